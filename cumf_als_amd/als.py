@@ -1,0 +1,302 @@
+"""Host-side mirror of the reference's operator surface, over the C ABI of libALS.so.
+
+* `do_als(...)` has the argument list and outputs of the reference's TensorFlow op
+  `DoAls` (`tensorflow/als_tf.cc:7-30,132-136`): numpy host arrays in, (thetaT, XT,
+  rmse) out.  It forwards to `cumf_doALS_ex` exactly as the TF op forwards to `doALS`.
+* `Plan`, `update_fused`, `get_hermitian`, `cg_solve`, `lu_solve`, `sse` are the
+  device-pointer entry points (torch CUDA tensors are used only as device memory).
+* `ALSEngine` keeps one dataset resident in HBM and steps half-iterations; it is what
+  bench.py times and what the multi-GPU driver (`cumf_als_amd.dist`) builds on.
+
+There is no CPU path here: every call lands in a HIP kernel of libALS.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _libmod
+
+SOLVER_CG, SOLVER_LU = 0, 1
+
+
+def _solver_id(solver) -> int:
+    if solver in (SOLVER_CG, "cg", "CG"):
+        return SOLVER_CG
+    if solver in (SOLVER_LU, "lu", "LU"):
+        return SOLVER_LU
+    raise ValueError(f"unknown solver {solver!r}")
+
+
+def _hostptr(a: np.ndarray, dtype) -> C.c_void_p:
+    if a.dtype != dtype or not a.flags["C_CONTIGUOUS"]:
+        raise TypeError(f"expected C-contiguous {np.dtype(dtype).name} array")
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def do_als(csrrow, csrcol, csrval, cscrow, csccol, cscval, coorow, coorowtest, coocoltest, coovaltest,
+           m, n, f, nnz, nnz_test, lambda_, iters, xbatch, thetabatch, deviceid=0, *,
+           thetat_init=None, xt_init=None, solver="cg", cg_iters=6, fused=True,
+           exact_test_grid=False, surpass_nan=False, quiet=True, return_log=False):
+    """`DoAls` (als_tf.cc): run `iters` ALS iterations on device `deviceid`.
+
+    Argument names follow the TF op's inputs: csrrow = CSR indptr (m+1), csrcol = CSR
+    indices, cscrow = CSC row ids (nnz), csccol = CSC indptr (n+1), coorow = row of each
+    CSR entry.  Returns (thetaT[n,f], XT[m,f], rmse) (+ rmse_log[iters,2] if asked).
+
+    Initial factors default to the CLI's initialisation (main.cpp:72-78 evaluated with
+    numpy's generator is NOT the same stream as libc rand(); pass `thetat_init` to
+    reproduce a particular start).
+    """
+    lib = _libmod.load()
+    if thetat_init is None:
+        rng = np.random.RandomState(0)
+        thetat = (0.2 * rng.random_sample((n, f))).astype(np.float32)
+    else:
+        thetat = np.array(thetat_init, dtype=np.float32, order="C", copy=True).reshape(n, f)
+    xt = (np.zeros((m, f), np.float32) if xt_init is None
+          else np.array(xt_init, dtype=np.float32, order="C", copy=True).reshape(m, f))
+    log = np.zeros((max(iters, 1), 2), np.float32)
+    csrrow = np.ascontiguousarray(csrrow, np.int32)
+    csccol = np.ascontiguousarray(csccol, np.int32)
+    if len(csrrow) != m + 1 or len(csccol) != n + 1:
+        raise ValueError("csrrow must hold m+1 and csccol n+1 row pointers")
+    args = [
+        _hostptr(csrrow, np.int32), _hostptr(np.ascontiguousarray(csrcol, np.int32), np.int32),
+        _hostptr(np.ascontiguousarray(csrval, np.float32), np.float32),
+        _hostptr(np.ascontiguousarray(cscrow, np.int32), np.int32), _hostptr(csccol, np.int32),
+        _hostptr(np.ascontiguousarray(cscval, np.float32), np.float32),
+        _hostptr(np.ascontiguousarray(coorow, np.int32), np.int32),
+        _hostptr(thetat, np.float32), _hostptr(xt, np.float32),
+        _hostptr(np.ascontiguousarray(coorowtest, np.int32), np.int32),
+        _hostptr(np.ascontiguousarray(coocoltest, np.int32), np.int32),
+        _hostptr(np.ascontiguousarray(coovaltest, np.float32), np.float32),
+    ]
+    rmse = lib.cumf_doALS_ex(*args, int(m), int(n), int(f), int(nnz), int(nnz_test), float(lambda_),
+                             int(iters), int(xbatch), int(thetabatch), int(deviceid),
+                             _solver_id(solver), int(cg_iters), int(bool(fused)), int(bool(exact_test_grid)),
+                             int(bool(surpass_nan)), int(bool(quiet)), _hostptr(log, np.float32))
+    if return_log:
+        return thetat, xt, float(rmse), log[:iters]
+    return thetat, xt, float(rmse)
+
+
+# ---------------------------------------------------------------------------------------
+# device-pointer entry points (torch tensors as device memory)
+# ---------------------------------------------------------------------------------------
+
+def _dp(t, dtype=None):
+    import torch
+
+    if t is None:
+        return None
+    if not t.is_cuda or not t.is_contiguous():
+        raise TypeError("expected a contiguous CUDA tensor")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"expected dtype {dtype}, got {t.dtype}")
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Plan:
+    """Work decomposition of one side (cumf_plan_create).  `rowptr` may be a numpy array
+    or a tensor (copied to host); int32 or int64."""
+
+    def __init__(self, rowptr, f: int, row_begin: int = 0, row_end: int | None = None, chunk: int = 0):
+        lib = _libmod.load()
+        if hasattr(rowptr, "detach"):
+            rowptr = rowptr.detach().cpu().numpy()
+        rowptr = np.ascontiguousarray(rowptr)
+        if rowptr.dtype == np.int64:
+            is64 = 1
+        elif rowptr.dtype == np.int32:
+            is64 = 0
+        else:
+            raise TypeError("rowptr must be int32 or int64")
+        self.rows = len(rowptr) - 1
+        self.row_begin = row_begin
+        self.row_end = self.rows if row_end is None else row_end
+        self.f = f
+        self._h = C.c_void_p()
+        _libmod.check(lib.cumf_plan_create(C.byref(self._h), rowptr.ctypes.data_as(C.c_void_p), is64, self.rows,
+                                           self.row_begin, self.row_end, f, chunk), "cumf_plan_create")
+        info = (C.c_long * 4)()
+        _libmod.check(lib.cumf_plan_info(self._h, info), "cumf_plan_info")
+        self.n_items, self.n_slots, self.n_multi_rows, self.chunk = (int(v) for v in info)
+
+    @property
+    def batch_rows(self) -> int:
+        return self.row_end - self.row_begin
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            _libmod.load().cumf_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def update_fused(plan: Plan, colidx, val, gather, update, lambda_: float, solver="cg", cg_iters: int = 6):
+    """One fused half-iteration over the plan's rows (cumf_als_update_fused)."""
+    import torch
+
+    lib = _libmod.load()
+    _libmod.check(lib.cumf_als_update_fused(plan._h, _dp(colidx, torch.int32), _dp(val, torch.float32),
+                                            _dp(gather, torch.float32), _dp(update, torch.float32), plan.f,
+                                            float(lambda_), _solver_id(solver), int(cg_iters), _stream()),
+                  "cumf_als_update_fused")
+    return update
+
+
+def get_hermitian(plan: Plan, colidx, val, gather, lambda_: float, tt=None, rhs=None, want_rhs=True):
+    """Materialise the Gram batch tt[rows,f,f] (+ rhs[rows,f]) of the plan's rows (cumf_get_hermitian)."""
+    import torch
+
+    lib = _libmod.load()
+    f, rows = plan.f, plan.batch_rows
+    if tt is None:
+        tt = torch.empty((rows, f, f), dtype=torch.float32, device=gather.device)
+    if rhs is None and want_rhs:
+        rhs = torch.empty((rows, f), dtype=torch.float32, device=gather.device)
+    _libmod.check(lib.cumf_get_hermitian(plan._h, _dp(colidx, torch.int32), _dp(val, torch.float32),
+                                         _dp(gather, torch.float32), _dp(tt, torch.float32),
+                                         _dp(rhs, torch.float32), f, float(lambda_), _stream()),
+                  "cumf_get_hermitian")
+    return tt, rhs
+
+
+def cg_solve(A, x, b, cg_iters: int = 6):
+    """Batched CG, x is the warm start and is overwritten (updateXWithCGHost, cg.h:30)."""
+    import torch
+
+    lib = _libmod.load()
+    f = b.shape[-1]
+    batch = b.numel() // f
+    _libmod.check(lib.cumf_cg_solve_batched(_dp(A, torch.float32), _dp(x, torch.float32), _dp(b, torch.float32),
+                                            batch, f, int(cg_iters), _stream()), "cumf_cg_solve_batched")
+    return x
+
+
+def lu_solve(A, b, x=None):
+    """Batched unpivoted LU solve (cublasSgetrfBatched + SgetrsBatched, als.cu:77,98)."""
+    import torch
+
+    lib = _libmod.load()
+    f = b.shape[-1]
+    batch = b.numel() // f
+    if x is None:
+        x = torch.empty_like(b)
+    _libmod.check(lib.cumf_lu_solve_batched(_dp(A, torch.float32), _dp(b, torch.float32), _dp(x, torch.float32),
+                                            batch, f, _stream()), "cumf_lu_solve_batched")
+    return x
+
+
+def sse(val, row, col, thetaT, XT, count: int | None = None, surpass_nan: bool = False, out=None):
+    """Sum of squared errors over the first `count` ratings -> 1-element fp64 tensor (cumf_sse)."""
+    import torch
+
+    lib = _libmod.load()
+    f = thetaT.shape[-1]
+    if count is None:
+        count = val.numel()
+    if out is None:
+        out = torch.zeros(1, dtype=torch.float64, device=val.device)
+    _libmod.check(lib.cumf_sse(_dp(val, torch.float32), _dp(row, torch.int32), _dp(col, torch.int32),
+                               _dp(thetaT, torch.float32), _dp(XT, torch.float32), int(count), f,
+                               int(bool(surpass_nan)), _dp(out, torch.float64), _stream()), "cumf_sse")
+    return out
+
+
+class ALSEngine:
+    """A dataset resident in HBM + the two half-iteration plans (single GPU).
+
+    `r` is a `cumf_als_amd.datagen.Ratings` already on the device.  Factors are the
+    reference's `thetaT` (n x f) and `XT` (m x f), row-contiguous f-vectors.
+    """
+
+    def __init__(self, r, f: int, lambda_: float, solver="cg", cg_iters: int = 6, x_batch: int = 1,
+                 theta_batch: int = 1, fused: bool = True, chunk: int = 0):
+        import torch
+
+        self.r, self.f, self.lam = r, f, float(lambda_)
+        self.solver, self.cg_iters, self.fused = solver, cg_iters, fused
+        self.m, self.n = r.m, r.n
+        self.device = r.csr_indices.device
+        self.x_plans = self._plans(r.csr_indptr, r.m, x_batch, chunk)
+        self.t_plans = self._plans(r.csc_indptr, r.n, theta_batch, chunk)
+        self.thetaT = torch.zeros((r.n, f), dtype=torch.float32, device=self.device)
+        self.XT = torch.zeros((r.m, f), dtype=torch.float32, device=self.device)
+        self._tt = None
+        self._rhs = None
+
+    def _plans(self, rowptr, rows, nbatch, chunk):
+        rp = rowptr.detach().cpu().numpy()
+        plans = []
+        for b in range(nbatch):  # als.cu:768-777
+            size = rows // nbatch if b != nbatch - 1 else rows - b * (rows // nbatch)
+            off = b * (rows // nbatch)
+            plans.append(Plan(rp, self.f, off, off + size, chunk))
+        return plans
+
+    def init_factors(self, thetaT=None, XT=None, seed: int = 0):
+        import torch
+
+        if thetaT is None:
+            g = torch.Generator(device="cpu")
+            g.manual_seed(seed)
+            thetaT = 0.2 * torch.rand((self.n, self.f), generator=g, dtype=torch.float32)
+        self.thetaT.copy_(torch.as_tensor(thetaT).reshape(self.n, self.f))
+        if XT is None:
+            self.XT.zero_()
+        else:
+            self.XT.copy_(torch.as_tensor(XT).reshape(self.m, self.f))
+
+    def _half(self, plans, colidx, val, gather, update):
+        import torch
+
+        for p in plans:
+            if self.fused:
+                update_fused(p, colidx, val, gather, update, self.lam, self.solver, self.cg_iters)
+            else:
+                rows = p.batch_rows
+                if self._tt is None or self._tt.shape[0] < rows:
+                    self._tt = torch.empty((rows, self.f, self.f), dtype=torch.float32, device=self.device)
+                    self._rhs = torch.empty((rows, self.f), dtype=torch.float32, device=self.device)
+                tt, rhs = self._tt[:rows], self._rhs[:rows]
+                get_hermitian(p, colidx, val, gather, self.lam, tt, rhs)
+                xb = update[p.row_begin:p.row_end]
+                if _solver_id(self.solver) == SOLVER_CG:
+                    cg_solve(tt, xb, rhs, self.cg_iters)
+                else:
+                    lu_solve(tt, rhs, xb)
+
+    def update_x(self):
+        """update X from thetaT over the CSR rows (als.cu:727-855)."""
+        self._half(self.x_plans, self.r.csr_indices, self.r.csr_data, self.thetaT, self.XT)
+
+    def update_theta(self):
+        """update Theta from XT over the CSC columns (als.cu:857-964)."""
+        self._half(self.t_plans, self.r.csc_indices, self.r.csc_data, self.XT, self.thetaT)
+
+    def rmse(self, exact_test_grid: bool = True, surpass_nan: bool = False):
+        """(train, test) RMSE as als.cu:966-1020."""
+        r = self.r
+        tr = sse(r.csr_data, r.coo_row, r.csr_indices, self.thetaT, self.XT, r.nnz, surpass_nan)
+        cnt = r.nnz_test if exact_test_grid else max(0, ((r.nnz_test - 1) // 256) * 256)
+        te = sse(r.test_data, r.test_row, r.test_col, self.thetaT, self.XT, cnt, surpass_nan)
+        return (float(tr.item() / max(r.nnz, 1)) ** 0.5, float(te.item() / max(r.nnz_test, 1)) ** 0.5)
+
+    def iterate(self, iters: int = 1):
+        for _ in range(iters):
+            self.update_x()
+            self.update_theta()

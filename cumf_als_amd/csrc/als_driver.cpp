@@ -1,0 +1,213 @@
+// als_driver.cpp -- `doALS`, the drop-in boundary (als.h:676-681, als.cu:662-1035).
+//
+// Same 22 host-pointer arguments, same in/out factors, same return value (final test
+// RMSE) and same stdout lines as the reference.  What changes underneath:
+//   * everything is uploaded ONCE and stays resident in HBM (the reference re-mallocs
+//     and re-uploads CSR, COO and the test set every iteration: als.cu:734-739,
+//     972-977, 999-1004);
+//   * a half-iteration is one fused pass (RHS + Gram + solve, cumf_als_update_fused);
+//     the reference's data flow (Gram batch in device memory, separate solver) is kept
+//     as the "unfused" path and is what f > 128 uses;
+//   * X_BATCH / THETA_BATCH keep their meaning (als.cu:768-777, 881-890): rows are
+//     processed in that many slices; results do not depend on them.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "als.h"
+#include "als_internal.h"
+#include "cumf_als_capi.h"
+
+namespace {
+
+#define DRV_CHECK(call)                                                                                         \
+  do {                                                                                                          \
+    hipError_t err__ = (hipError_t)(call);                                                                      \
+    if (err__ != hipSuccess) {                                                                                  \
+      /* error convention of als.h:628-639: message to stderr, then exit */                                    \
+      fprintf(stderr, "HIP Error:\nFile = %s\nLine = %d\nReason = %s\n", __FILE__, __LINE__,                    \
+              hipGetErrorString(err__));                                                                        \
+      exit(EXIT_FAILURE);                                                                                       \
+    }                                                                                                           \
+  } while (0)
+
+template <typename T>
+T* to_device(const T* host, size_t count) {
+  T* d = nullptr;
+  if (count == 0) count = 1;
+  DRV_CHECK(hipMalloc(reinterpret_cast<void**>(&d), count * sizeof(T)));
+  if (host) DRV_CHECK(hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice));
+  return d;
+}
+
+struct Side {
+  // one side of the factorisation: rows x cols CSR (CSC of R passed as CSR of R^T, als.cu:867-869)
+  const int* rowptr_host;
+  const int* d_colidx;
+  const float* d_val;
+  long rows;
+  int nbatch;
+  std::vector<cumf_plan_t*> plans;
+  std::vector<long> offset, size;
+};
+
+void make_side(Side& s, int f) {
+  for (int b = 0; b < s.nbatch; ++b) {
+    // als.cu:768-777
+    const long bs = (b != s.nbatch - 1) ? s.rows / s.nbatch : s.rows - (long)b * (s.rows / s.nbatch);
+    const long off = (long)b * (s.rows / s.nbatch);
+    cumf_plan_t* p = nullptr;
+    DRV_CHECK(cumf_plan_create(&p, s.rowptr_host, 0, s.rows, off, off + bs, f, 0));
+    s.plans.push_back(p);
+    s.offset.push_back(off);
+    s.size.push_back(bs);
+  }
+}
+
+int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+}  // namespace
+
+extern "C" float cumf_doALS_ex(const int* csrRowIndexHostPtr, const int* csrColIndexHostPtr,
+                               const float* csrValHostPtr, const int* cscRowIndexHostPtr,
+                               const int* cscColIndexHostPtr, const float* cscValHostPtr,
+                               const int* cooRowIndexHostPtr, float* thetaTHost, float* XTHost,
+                               const int* cooRowIndexTestHostPtr, const int* cooColIndexTestHostPtr,
+                               const float* cooValHostTestPtr, int m, int n, int f, long nnz, long nnz_test,
+                               float lambda, int ITERS, int X_BATCH, int THETA_BATCH, int DEVICEID, int solver,
+                               int cg_iters, int fused, int exact_test_grid, int surpass_nan, int quiet,
+                               float* rmse_log) {
+  DRV_CHECK(hipSetDevice(DEVICEID));
+  if (!quiet) printf("*******parameters: m: %d, n:  %d, f: %d, nnz: %ld \n", m, n, f, nnz);
+  if (X_BATCH < 1) X_BATCH = 1;
+  if (THETA_BATCH < 1) THETA_BATCH = 1;
+  if (cumf::nb_for_f(f) > cumf::kMaxFusedNB) fused = 0;  // LDS-resident solve needs f <= 128
+
+  if (!quiet) printf("*******start allocating memory on GPU...\n");
+  int* csrColIndex = to_device(csrColIndexHostPtr, (size_t)nnz);
+  float* csrVal = to_device(csrValHostPtr, (size_t)nnz);
+  int* cscRowIndex = to_device(cscRowIndexHostPtr, (size_t)nnz);
+  float* cscVal = to_device(cscValHostPtr, (size_t)nnz);
+  int* cooRowIndex = to_device(cooRowIndexHostPtr, (size_t)nnz);
+  int* cooRowIndex_test = to_device(cooRowIndexTestHostPtr, (size_t)nnz_test);
+  int* cooColIndex_test = to_device(cooColIndexTestHostPtr, (size_t)nnz_test);
+  float* cooVal_test = to_device(cooValHostTestPtr, (size_t)nnz_test);
+  if (!quiet) printf("*******start copying memory to GPU...\n");
+  float* thetaT = to_device(thetaTHost, (size_t)n * f);
+  float* XT = to_device(XTHost, (size_t)m * f);
+  double* d_sse = to_device<double>(nullptr, 2);
+
+  Side sx{csrRowIndexHostPtr, csrColIndex, csrVal, m, X_BATCH, {}, {}, {}};
+  Side st{cscColIndexHostPtr, cscRowIndex, cscVal, n, THETA_BATCH, {}, {}, {}};
+  make_side(sx, f);
+  make_side(st, f);
+
+  // unfused path: Gram batch `tt` (als.cu:782,897) + RHS (ythetaT / yTXT, als.cu:746,864)
+  float *tt = nullptr, *rhs = nullptr;
+  if (!fused) {
+    long maxb = 0;
+    for (long s : sx.size) maxb = s > maxb ? s : maxb;
+    for (long s : st.size) maxb = s > maxb ? s : maxb;
+    tt = to_device<float>(nullptr, (size_t)maxb * f * f);
+    rhs = to_device<float>(nullptr, (size_t)maxb * f);
+  }
+
+  auto half_iteration = [&](Side& s, const float* gather, float* update) {
+    for (int b = 0; b < s.nbatch; ++b) {
+      if (fused) {
+        if (solver == CUMF_SOLVER_CG && !quiet) printf("\tCG solver with fp32.\n");
+        DRV_CHECK(cumf_als_update_fused(s.plans[b], s.d_colidx, s.d_val, gather, update, f, lambda, solver,
+                                        cg_iters, nullptr));
+      } else {
+        DRV_CHECK(cumf_get_hermitian(s.plans[b], s.d_colidx, s.d_val, gather, tt, rhs, f, lambda, nullptr));
+        float* xb = update + (size_t)s.offset[b] * f;
+        if (solver == CUMF_SOLVER_CG) {
+          if (!quiet) printf("\tCG solver with fp32.\n");
+          DRV_CHECK(cumf_cg_solve_batched(tt, xb, rhs, s.size[b], f, cg_iters, nullptr));
+        } else {
+          DRV_CHECK(cumf_lu_solve_batched(tt, rhs, xb, s.size[b], f, nullptr));
+        }
+      }
+    }
+  };
+
+  float final_rmse = 0;
+  if (!quiet) printf("*******start iterations...\n");
+  for (int iter = 0; iter < ITERS; iter++) {
+    half_iteration(sx, thetaT, XT);  // update X      (als.cu:727-855)
+    half_iteration(st, XT, thetaT);  // update Theta  (als.cu:857-964)
+
+    // RMSE (als.cu:966-1020).  The test grid of the reference is (nnz_test-1)/256 blocks
+    // -- one short of covering the set (als.cu:1006) -- yet divides by nnz_test.
+    long count_test = exact_test_grid ? nnz_test : ((nnz_test - 1) / 256) * 256;
+    if (count_test < 0) count_test = 0;
+    DRV_CHECK(cumf_sse(csrVal, cooRowIndex, csrColIndex, thetaT, XT, nnz, f, surpass_nan, d_sse, nullptr));
+    DRV_CHECK(cumf_sse(cooVal_test, cooRowIndex_test, cooColIndex_test, thetaT, XT, count_test, f, surpass_nan,
+                       d_sse + 1, nullptr));
+    double sse[2];
+    DRV_CHECK(hipMemcpy(sse, d_sse, sizeof(sse), hipMemcpyDeviceToHost));
+    const float rmse_train = (float)sqrt(sse[0] / (double)nnz);
+    final_rmse = (float)sqrt(sse[1] / (double)nnz_test);
+    if (!quiet) {
+      printf("--------- Train RMSE in iter %d: %f\n", iter, rmse_train);
+      printf("--------- Test RMSE in iter %d: %f\n", iter, final_rmse);
+    }
+    if (rmse_log) {
+      rmse_log[2 * iter] = rmse_train;
+      rmse_log[2 * iter + 1] = final_rmse;
+    }
+  }
+  DRV_CHECK(hipDeviceSynchronize());
+  // copy feature vectors back to host (als.cu:1024-1025)
+  DRV_CHECK(hipMemcpy(thetaTHost, thetaT, (size_t)n * f * sizeof(float), hipMemcpyDeviceToHost));
+  DRV_CHECK(hipMemcpy(XTHost, XT, (size_t)m * f * sizeof(float), hipMemcpyDeviceToHost));
+
+  for (cumf_plan_t* p : sx.plans) cumf_plan_destroy(p);
+  for (cumf_plan_t* p : st.plans) cumf_plan_destroy(p);
+  void* bufs[] = {csrColIndex, csrVal, cscRowIndex, cscVal, cooRowIndex, cooRowIndex_test, cooColIndex_test,
+                  cooVal_test, thetaT,  XT,      d_sse,  tt,          rhs};
+  for (void* q : bufs)
+    if (q) DRV_CHECK(hipFree(q));
+  // the device is NOT reset here (als.cu:1031-1033: "WARN: do not call cudaDeviceReset inside ALS()")
+  return final_rmse;
+}
+
+extern "C" float cumf_doALS(const int* csrRowIndexHostPtr, const int* csrColIndexHostPtr, const float* csrValHostPtr,
+                            const int* cscRowIndexHostPtr, const int* cscColIndexHostPtr, const float* cscValHostPtr,
+                            const int* cooRowIndexHostPtr, float* thetaTHost, float* XTHost,
+                            const int* cooRowIndexTestHostPtr, const int* cooColIndexTestHostPtr,
+                            const float* cooValHostTestPtr, const int m, const int n, const int f, const long nnz,
+                            const long nnz_test, const float lambda, const int ITERS, const int X_BATCH,
+                            const int THETA_BATCH, const int DEVICEID) {
+  // run-time versions of the compile-time switches of als.cu:25-33
+  const char* s = getenv("CUMF_ALS_SOLVER");
+  const int solver = (s && (strcmp(s, "lu") == 0 || strcmp(s, "LU") == 0)) ? CUMF_SOLVER_LU : CUMF_SOLVER_CG;
+  const char* pth = getenv("CUMF_ALS_PATH");
+  const int fused = !(pth && strcmp(pth, "unfused") == 0);
+  return cumf_doALS_ex(csrRowIndexHostPtr, csrColIndexHostPtr, csrValHostPtr, cscRowIndexHostPtr,
+                       cscColIndexHostPtr, cscValHostPtr, cooRowIndexHostPtr, thetaTHost, XTHost,
+                       cooRowIndexTestHostPtr, cooColIndexTestHostPtr, cooValHostTestPtr, m, n, f, nnz, nnz_test,
+                       lambda, ITERS, X_BATCH, THETA_BATCH, DEVICEID, solver, env_int("CUMF_ALS_CG_ITERS", 6), fused,
+                       env_int("CUMF_ALS_EXACT_TEST_GRID", 0), env_int("CUMF_ALS_SURPASS_NAN", 0),
+                       env_int("CUMF_ALS_QUIET", 0), nullptr);
+}
+
+// C++ linkage, the reference's own symbol (_Z5doALSPKiS0_PKfS0_S0_S2_S0_PfS3_S0_S0_S2_iiillfiiii).
+float doALS(const int* csrRowIndexHostPtr, const int* csrColIndexHostPtr, const float* csrValHostPtr,
+            const int* cscRowIndexHostPtr, const int* cscColIndexHostPtr, const float* cscValHostPtr,
+            const int* cooRowIndexHostPtr, float* thetaTHost, float* XTHost, const int* cooRowIndexTestHostPtr,
+            const int* cooColIndexTestHostPtr, const float* cooValHostTestPtr, const int m, const int n, const int f,
+            const long nnz, const long nnz_test, const float lambda, const int ITERS, const int X_BATCH,
+            const int THETA_BATCH, const int DEVICEID) {
+  return cumf_doALS(csrRowIndexHostPtr, csrColIndexHostPtr, csrValHostPtr, cscRowIndexHostPtr, cscColIndexHostPtr,
+                    cscValHostPtr, cooRowIndexHostPtr, thetaTHost, XTHost, cooRowIndexTestHostPtr,
+                    cooColIndexTestHostPtr, cooValHostTestPtr, m, n, f, nnz, nnz_test, lambda, ITERS, X_BATCH,
+                    THETA_BATCH, DEVICEID);
+}

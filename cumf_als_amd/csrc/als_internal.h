@@ -1,0 +1,68 @@
+// als_internal.h -- declarations shared by the HIP kernels and the host side of libALS.so.
+#ifndef CUMF_ALS_INTERNAL_H_
+#define CUMF_ALS_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+
+namespace cumf {
+
+constexpr int kThreads = 256;   // 4 waves of 64
+constexpr int kStage = 32;      // gathered factor rows per LDS stage
+constexpr int kVecLd = 128;     // pitch of the CG vectors in LDS (fused solve needs f <= 128)
+constexpr int kMaxFusedNB = 9;  // f <= 128  ->  NB = f / 16 + 1 <= 9
+constexpr int kMaxF = 207;      // NB <= 13
+
+enum { kModeCG = 0, kModeLU = 1, kModeMaterialize = 2 };
+
+// Feature blocks of 16 including the slot that carries the rating value (RHS).
+__host__ __device__ constexpr int nb_for_f(int f) { return f / 16 + 1; }
+__host__ __device__ constexpr size_t solve_g_floats(int f) { return ((size_t)f * (f + 1) + 3) & ~(size_t)3; }
+
+struct KernelArgs {
+  // plan items (one workgroup each)
+  const int* item_row;
+  const long long* item_begin;
+  const int* item_len;
+  const int* item_slot;
+  const int* item_rowlen;
+  // chunked rows (reduce kernel)
+  const int* mrow_row;
+  const int* mrow_slot0;
+  const int* mrow_nslots;
+  const int* mrow_rowlen;
+  float* part;
+  // matrix + factors
+  const int* colidx;
+  const float* val;
+  const float* gather;
+  float* update;
+  // materialise outputs
+  float* tt;
+  float* rhs;
+  long long row_begin;
+  int f;
+  float lambda;
+  int cg_iters;
+};
+
+hipError_t launch_half_iteration(const KernelArgs& a, int mode, long n_items, long n_mrows, hipStream_t stream);
+hipError_t launch_solve_batched(const float* A, const float* b, float* x, long batch, int f, int mode, int cg_iters,
+                                hipStream_t stream);
+hipError_t launch_sse(const float* val, const int* row, const int* col, const float* thetaT, const float* XT,
+                      long count, int f, int surpass_nan, double* out, hipStream_t stream);
+
+}  // namespace cumf
+
+#define CUMF_HIP_CHECK(call)                                                                          \
+  do {                                                                                                \
+    hipError_t err__ = (call);                                                                        \
+    if (err__ != hipSuccess) {                                                                        \
+      fprintf(stderr, "HIP Error:\nFile = %s\nLine = %d\nReason = %s\n", __FILE__, __LINE__,          \
+              hipGetErrorString(err__));                                                              \
+      return (int)err__;                                                                              \
+    }                                                                                                 \
+  } while (0)
+
+#endif  // CUMF_ALS_INTERNAL_H_

@@ -1,0 +1,269 @@
+// als_plan.cpp -- static work decomposition of one ALS half-iteration + the C ABI of
+// the device-pointer entry points (include/cumf_als_capi.h).
+//
+// The reference launches one CUDA block per row (als.cu:449) inside a per-batch loop
+// (als.cu:768-777, 881-890).  On the Netflix X side that is 17 770 rows with up to
+// ~230k ratings each over 256 CUs: the tail row alone would run for milliseconds.
+// The plan cuts every row into chunks of at most `chunk` ratings ("items"), orders
+// the items longest-first and gives each chunk of a split row a slot in a partial
+// tile buffer that the reduce kernel sums in slot order (deterministic).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <numeric>
+#include <vector>
+
+#include "als_internal.h"
+#include "cumf_als_capi.h"
+
+using namespace cumf;
+
+struct cumf_plan {
+  long rows = 0, row_begin = 0, row_end = 0;
+  int f = 0, nb = 0, chunk = 0;
+  long n_items = 0, n_slots = 0, n_mrows = 0;
+  int* d_item_row = nullptr;
+  long long* d_item_begin = nullptr;
+  int* d_item_len = nullptr;
+  int* d_item_slot = nullptr;
+  int* d_item_rowlen = nullptr;
+  int* d_mrow_row = nullptr;
+  int* d_mrow_slot0 = nullptr;
+  int* d_mrow_nslots = nullptr;
+  int* d_mrow_rowlen = nullptr;
+  float* d_part = nullptr;
+};
+
+namespace {
+
+int default_chunk(int f) {
+  // A chunk of C ratings costs ~C/4 * TPW MFMAs of 32 cycles per wave; 2048 ratings at
+  // f = 100 is ~55 us per workgroup -- small against a half-iteration, large against
+  // the 28 KiB partial-tile write it may cause.  Must be a multiple of kStage.
+  (void)f;
+  const char* e = getenv("CUMF_ALS_CHUNK");
+  int c = e ? atoi(e) : 2048;
+  if (c < kStage) c = kStage;
+  return (c / kStage) * kStage;
+}
+
+template <typename T>
+hipError_t upload(T** dst, const std::vector<T>& src) {
+  *dst = nullptr;
+  if (src.empty()) return hipSuccess;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(dst), src.size() * sizeof(T));
+  if (e != hipSuccess) return e;
+  return hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice);
+}
+
+}  // namespace
+
+extern "C" int cumf_plan_create(cumf_plan_t** out, const void* rowptr_host, int rowptr_is_64, long rows,
+                                long row_begin, long row_end, int f, int chunk) {
+  if (!out || !rowptr_host || rows < 0 || row_begin < 0 || row_end > rows || row_begin > row_end) {
+    fprintf(stderr, "cumf_plan_create: invalid arguments\n");
+    return (int)hipErrorInvalidValue;
+  }
+  if (f <= 0 || f > kMaxF || (f % 2) != 0) {
+    fprintf(stderr, "cumf_plan_create: f = %d unsupported (need even f <= %d)\n", f, kMaxF);
+    return (int)hipErrorInvalidValue;
+  }
+  if (chunk <= 0) chunk = default_chunk(f);
+  chunk = std::max(kStage, (chunk / kStage) * kStage);
+
+  auto rp = [&](long i) -> long long {
+    return rowptr_is_64 ? static_cast<const long long*>(rowptr_host)[i]
+                        : static_cast<long long>(static_cast<const int*>(rowptr_host)[i]);
+  };
+
+  std::vector<int> item_row, item_len, item_slot, item_rowlen;
+  std::vector<long long> item_begin;
+  std::vector<int> mrow_row, mrow_slot0, mrow_nslots, mrow_rowlen;
+  long n_slots = 0;
+  for (long u = row_begin; u < row_end; ++u) {
+    const long long s = rp(u), e = rp(u + 1);
+    const long long len = e - s;
+    if (len < 0 || len > 0x7fffffffLL) {
+      fprintf(stderr, "cumf_plan_create: row %ld has invalid length %lld\n", u, len);
+      return (int)hipErrorInvalidValue;
+    }
+    if (len <= chunk) {
+      item_row.push_back((int)u);
+      item_begin.push_back(s);
+      item_len.push_back((int)len);
+      item_slot.push_back(-1);
+      item_rowlen.push_back((int)len);
+    } else {
+      const int nchunks = (int)((len + chunk - 1) / chunk);
+      mrow_row.push_back((int)u);
+      mrow_slot0.push_back((int)n_slots);
+      mrow_nslots.push_back(nchunks);
+      mrow_rowlen.push_back((int)len);
+      for (int c = 0; c < nchunks; ++c) {
+        const long long b = s + (long long)c * chunk;
+        item_row.push_back((int)u);
+        item_begin.push_back(b);
+        item_len.push_back((int)std::min<long long>(chunk, e - b));
+        item_slot.push_back((int)(n_slots + c));
+        item_rowlen.push_back((int)len);
+      }
+      n_slots += nchunks;
+    }
+  }
+  // longest-first (stable => deterministic): the hardware dispatches workgroups in
+  // index order, so the short items fill the tail.
+  std::vector<long> order(item_row.size());
+  std::iota(order.begin(), order.end(), 0L);
+  std::stable_sort(order.begin(), order.end(), [&](long a, long b) { return item_len[a] > item_len[b]; });
+  auto permute = [&](auto& v) {
+    auto copy = v;
+    for (size_t i = 0; i < order.size(); ++i) v[i] = copy[order[i]];
+  };
+  permute(item_row);
+  permute(item_begin);
+  permute(item_len);
+  permute(item_slot);
+  permute(item_rowlen);
+
+  cumf_plan* p = new cumf_plan();
+  p->rows = rows;
+  p->row_begin = row_begin;
+  p->row_end = row_end;
+  p->f = f;
+  p->nb = nb_for_f(f);
+  p->chunk = chunk;
+  p->n_items = (long)item_row.size();
+  p->n_slots = n_slots;
+  p->n_mrows = (long)mrow_row.size();
+  *out = p;
+  CUMF_HIP_CHECK(upload(&p->d_item_row, item_row));
+  CUMF_HIP_CHECK(upload(&p->d_item_begin, item_begin));
+  CUMF_HIP_CHECK(upload(&p->d_item_len, item_len));
+  CUMF_HIP_CHECK(upload(&p->d_item_slot, item_slot));
+  CUMF_HIP_CHECK(upload(&p->d_item_rowlen, item_rowlen));
+  CUMF_HIP_CHECK(upload(&p->d_mrow_row, mrow_row));
+  CUMF_HIP_CHECK(upload(&p->d_mrow_slot0, mrow_slot0));
+  CUMF_HIP_CHECK(upload(&p->d_mrow_nslots, mrow_nslots));
+  CUMF_HIP_CHECK(upload(&p->d_mrow_rowlen, mrow_rowlen));
+  if (n_slots > 0) {
+    const size_t tiles = (size_t)p->nb * (p->nb + 1) / 2;
+    CUMF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p->d_part), (size_t)n_slots * tiles * 256 * sizeof(float)));
+  }
+  return 0;
+}
+
+extern "C" int cumf_plan_destroy(cumf_plan_t* p) {
+  if (!p) return 0;
+  void* ptrs[] = {p->d_item_row,  p->d_item_begin,  p->d_item_len,    p->d_item_slot,   p->d_item_rowlen,
+                  p->d_mrow_row,  p->d_mrow_slot0,  p->d_mrow_nslots, p->d_mrow_rowlen, p->d_part};
+  for (void* q : ptrs)
+    if (q) (void)hipFree(q);
+  delete p;
+  return 0;
+}
+
+extern "C" int cumf_plan_info(const cumf_plan_t* p, long info[4]) {
+  if (!p || !info) return (int)hipErrorInvalidValue;
+  info[0] = p->n_items;
+  info[1] = p->n_slots;
+  info[2] = p->n_mrows;
+  info[3] = p->chunk;
+  return 0;
+}
+
+namespace {
+
+KernelArgs base_args(const cumf_plan_t* p, const int* colidx, const float* val, const float* gather, int f,
+                     float lambda) {
+  KernelArgs a{};
+  a.item_row = p->d_item_row;
+  a.item_begin = p->d_item_begin;
+  a.item_len = p->d_item_len;
+  a.item_slot = p->d_item_slot;
+  a.item_rowlen = p->d_item_rowlen;
+  a.mrow_row = p->d_mrow_row;
+  a.mrow_slot0 = p->d_mrow_slot0;
+  a.mrow_nslots = p->d_mrow_nslots;
+  a.mrow_rowlen = p->d_mrow_rowlen;
+  a.part = p->d_part;
+  a.colidx = colidx;
+  a.val = val;
+  a.gather = gather;
+  a.row_begin = p->row_begin;
+  a.f = f;
+  a.lambda = lambda;
+  return a;
+}
+
+}  // namespace
+
+extern "C" int cumf_als_update_fused(const cumf_plan_t* p, const int* colidx, const float* val, const float* gather,
+                                     float* update, int f, float lambda, int solver, int cg_iters, void* stream) {
+  if (!p || f != p->f) {
+    fprintf(stderr, "cumf_als_update_fused: plan/f mismatch\n");
+    return (int)hipErrorInvalidValue;
+  }
+  if (nb_for_f(f) > kMaxFusedNB) {
+    fprintf(stderr, "cumf_als_update_fused: f = %d > 128 needs the materialising path "
+                    "(cumf_get_hermitian + cumf_*_solve_batched)\n", f);
+    return (int)hipErrorInvalidValue;
+  }
+  KernelArgs a = base_args(p, colidx, val, gather, f, lambda);
+  a.update = update;
+  a.cg_iters = cg_iters;
+  const int mode = (solver == CUMF_SOLVER_LU) ? kModeLU : kModeCG;
+  CUMF_HIP_CHECK(launch_half_iteration(a, mode, p->n_items, p->n_mrows, static_cast<hipStream_t>(stream)));
+  return 0;
+}
+
+extern "C" int cumf_get_hermitian(const cumf_plan_t* p, const int* colidx, const float* val, const float* gather,
+                                  float* tt, float* rhs, int f, float lambda, void* stream) {
+  if (!p || f != p->f) {
+    fprintf(stderr, "cumf_get_hermitian: plan/f mismatch\n");
+    return (int)hipErrorInvalidValue;
+  }
+  KernelArgs a = base_args(p, colidx, val, gather, f, lambda);
+  a.tt = tt;
+  a.rhs = rhs;
+  CUMF_HIP_CHECK(launch_half_iteration(a, kModeMaterialize, p->n_items, p->n_mrows, static_cast<hipStream_t>(stream)));
+  return 0;
+}
+
+extern "C" int cumf_cg_solve_batched(const float* A, float* x, const float* b, long batch, int f, int cg_iters,
+                                     void* stream) {
+  if (f <= 0 || f > 256) return (int)hipErrorInvalidValue;
+  CUMF_HIP_CHECK(launch_solve_batched(A, b, x, batch, f, kModeCG, cg_iters, static_cast<hipStream_t>(stream)));
+  return 0;
+}
+
+extern "C" int cumf_lu_solve_batched(const float* A, const float* b, float* x, long batch, int f, void* stream) {
+  if (f <= 0 || f > 200) {
+    fprintf(stderr, "cumf_lu_solve_batched: f = %d unsupported (LDS-resident system needs f <= 200)\n", f);
+    return (int)hipErrorInvalidValue;
+  }
+  CUMF_HIP_CHECK(launch_solve_batched(A, b, x, batch, f, kModeLU, 0, static_cast<hipStream_t>(stream)));
+  return 0;
+}
+
+extern "C" int cumf_sse(const float* val, const int* row, const int* col, const float* thetaT, const float* XT,
+                        long count, int f, int surpass_nan, double* sse_out, void* stream) {
+  CUMF_HIP_CHECK(launch_sse(val, row, col, thetaT, XT, count, f, surpass_nan, sse_out, static_cast<hipStream_t>(stream)));
+  return 0;
+}
+
+extern "C" int cumf_als_version(void) { return 100; }
+extern "C" const char* cumf_als_arch(void) { return "gfx950"; }
+
+// C++-linkage drop-in of the reference's inner solver API (cg.h:30, cg.cu:682-686):
+// device pointers, synchronous, aborts on error like cudaCheckError (als.h:667-674).
+void updateXWithCGHost(float* A, float* x, float* b, const int batchSize, const int f, const float cgIter) {
+  int rc = cumf_cg_solve_batched(A, x, b, batchSize, f, (int)cgIter, nullptr);
+  hipError_t e = hipDeviceSynchronize();
+  if (rc != 0 || e != hipSuccess) {
+    fprintf(stderr, "updateXWithCGHost failed: %s\n", hipGetErrorString(rc ? (hipError_t)rc : e));
+    exit(EXIT_FAILURE);
+  }
+}

@@ -1,0 +1,87 @@
+"""ctypes loader of `cumf_als_amd/csrc/libALS.so` (the C ABI of include/cumf_als_capi.h).
+
+The library is the product: there is no Python or CPU fallback.  `load()` raises
+when the shared object is missing or lacks a declared symbol.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libALS.so")
+MAIN_PATH = os.path.join(CSRC, "main")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+
+# every extern "C" symbol declared in include/cumf_als_capi.h
+C_SYMBOLS = [
+    "cumf_doALS", "cumf_doALS_ex", "cumf_plan_create", "cumf_plan_destroy", "cumf_plan_info",
+    "cumf_als_update_fused", "cumf_get_hermitian", "cumf_cg_solve_batched", "cumf_lu_solve_batched",
+    "cumf_sse", "cumf_als_version", "cumf_als_arch",
+]
+# C++-linkage drop-in symbols (include/als.h, include/cg.h) under the reference's mangled names
+CXX_SYMBOLS = [
+    "_Z5doALSPKiS0_PKfS0_S0_S2_S0_PfS3_S0_S0_S2_iiillfiiii",
+    "_Z17updateXWithCGHostPfS_S_iif",
+]
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile libALS.so and ./main for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force:
+        subprocess.run(["make", "-s", "-C", CSRC, "clean"], check=True)
+    subprocess.run(["make", "-s", "-C", CSRC, "build"], check=True)
+    return LIB_PATH
+
+
+def load():
+    """Load libALS.so; raise (never fall back) if it is absent or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  cumf_als_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    missing = [s for s in C_SYMBOLS + CXX_SYMBOLS if not hasattr(lib, s)]
+    if missing:
+        raise RuntimeError(f"{LIB_PATH} lacks symbols declared in include/: {missing}")
+
+    vp, ip, fp = C.c_void_p, C.c_void_p, C.c_void_p
+    lib.cumf_plan_create.restype = C.c_int
+    lib.cumf_plan_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_long, C.c_long, C.c_long,
+                                     C.c_int, C.c_int]
+    lib.cumf_plan_destroy.restype = C.c_int
+    lib.cumf_plan_destroy.argtypes = [C.c_void_p]
+    lib.cumf_plan_info.restype = C.c_int
+    lib.cumf_plan_info.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
+    lib.cumf_als_update_fused.restype = C.c_int
+    lib.cumf_als_update_fused.argtypes = [vp, ip, fp, fp, fp, C.c_int, C.c_float, C.c_int, C.c_int, vp]
+    lib.cumf_get_hermitian.restype = C.c_int
+    lib.cumf_get_hermitian.argtypes = [vp, ip, fp, fp, fp, fp, C.c_int, C.c_float, vp]
+    lib.cumf_cg_solve_batched.restype = C.c_int
+    lib.cumf_cg_solve_batched.argtypes = [fp, fp, fp, C.c_long, C.c_int, C.c_int, vp]
+    lib.cumf_lu_solve_batched.restype = C.c_int
+    lib.cumf_lu_solve_batched.argtypes = [fp, fp, fp, C.c_long, C.c_int, vp]
+    lib.cumf_sse.restype = C.c_int
+    lib.cumf_sse.argtypes = [fp, ip, ip, fp, fp, C.c_long, C.c_int, C.c_int, vp, vp]
+    lib.cumf_als_version.restype = C.c_int
+    lib.cumf_als_arch.restype = C.c_char_p
+    host_args = [vp] * 12 + [C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_float, C.c_int, C.c_int, C.c_int,
+                             C.c_int]
+    lib.cumf_doALS.restype = C.c_float
+    lib.cumf_doALS.argtypes = host_args
+    lib.cumf_doALS_ex.restype = C.c_float
+    lib.cumf_doALS_ex.argtypes = host_args + [C.c_int] * 6 + [vp]
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed with HIP error {rc}")

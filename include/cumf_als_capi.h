@@ -1,0 +1,124 @@
+/*
+ * cumf_als_capi.h -- C ABI of libALS.so, the MI355X-native ALS solve path.
+ *
+ * Plain pointers and sizes only; no torch / C++ types cross this boundary.
+ * Every entry point names the reference interface (file:line under the
+ * cuMF/cumf_als tree) it replaces.  Device pointers are HIP device pointers of
+ * the calling process; `stream` is a hipStream_t passed as void* (NULL = the
+ * default stream).  All entry points return 0 on success and a non-zero HIP
+ * error code on failure after printing file/line to stderr; they never fall
+ * back to a CPU path.
+ */
+#ifndef CUMF_ALS_CAPI_H_
+#define CUMF_ALS_CAPI_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Solver selection: the reference chooses at compile time with `#define USE_CG`
+ * (als.cu:28); here it is a run-time argument. */
+enum { CUMF_SOLVER_CG = 0, CUMF_SOLVER_LU = 1 };
+
+/*
+ * extern "C" alias of `float doALS(...)` (als.h:676-681, als.cu:662-1035).
+ * Same 22 arguments, same meaning, same in/out behaviour of thetaTHost / XTHost,
+ * same stdout lines (als.cu:670,830,991,1019).  HOST pointers.  Solver, CG
+ * iteration count and RMSE compat flags come from the environment
+ * (CUMF_ALS_SOLVER=cg|lu, CUMF_ALS_CG_ITERS, CUMF_ALS_EXACT_TEST_GRID,
+ * CUMF_ALS_SURPASS_NAN, CUMF_ALS_PATH=fused|unfused) -- see INTEGRATION.md.
+ */
+float cumf_doALS(const int* csrRowIndexHostPtr, const int* csrColIndexHostPtr, const float* csrValHostPtr,
+                 const int* cscRowIndexHostPtr, const int* cscColIndexHostPtr, const float* cscValHostPtr,
+                 const int* cooRowIndexHostPtr, float* thetaTHost, float* XTHost,
+                 const int* cooRowIndexTestHostPtr, const int* cooColIndexTestHostPtr,
+                 const float* cooValHostTestPtr, const int m, const int n, const int f, const long nnz,
+                 const long nnz_test, const float lambda, const int ITERS, const int X_BATCH,
+                 const int THETA_BATCH, const int DEVICEID);
+
+/* doALS with the compile-time switches of als.cu:25-33 exposed as arguments.
+ * rmse_log (may be NULL): 2*ITERS floats, (train, test) per iteration. */
+float cumf_doALS_ex(const int* csrRowIndexHostPtr, const int* csrColIndexHostPtr, const float* csrValHostPtr,
+                    const int* cscRowIndexHostPtr, const int* cscColIndexHostPtr, const float* cscValHostPtr,
+                    const int* cooRowIndexHostPtr, float* thetaTHost, float* XTHost,
+                    const int* cooRowIndexTestHostPtr, const int* cooColIndexTestHostPtr,
+                    const float* cooValHostTestPtr, int m, int n, int f, long nnz, long nnz_test,
+                    float lambda, int ITERS, int X_BATCH, int THETA_BATCH, int DEVICEID,
+                    int solver, int cg_iters, int fused, int exact_test_grid, int surpass_nan,
+                    int quiet, float* rmse_log);
+
+/* ------------------------------------------------------------------------
+ * Half-iteration plan: the static work decomposition of one side of the
+ * factorisation (update X over CSR rows, or update Theta over CSC columns).
+ * Replaces the per-iteration launch bookkeeping of als.cu:760-855 / 876-964:
+ * rows are cut into chunks of at most `chunk` ratings so that a heavy row
+ * (Netflix X side: up to ~230k ratings) is spread over many workgroups instead
+ * of one CUDA block per row (als.cu:449).
+ * ------------------------------------------------------------------------ */
+typedef struct cumf_plan cumf_plan_t;
+
+/* rowptr_host: HOST row pointers of the rows [0, rows] (int32, or int64 when
+ * rowptr_is_64 != 0 -- hugewiki.cu:2266 keeps them unsigned for nnz > 2^31).
+ * Only rows [row_begin, row_end) are planned (the X_BATCH / THETA_BATCH slices of
+ * als.cu:768-777, 881-890).  chunk <= 0 picks the default for f. */
+int cumf_plan_create(cumf_plan_t** plan, const void* rowptr_host, int rowptr_is_64, long rows,
+                     long row_begin, long row_end, int f, int chunk);
+int cumf_plan_destroy(cumf_plan_t* plan);
+/* counts for tests/diagnostics: [0]=items, [1]=partial slots, [2]=multi-chunk rows, [3]=chunk */
+int cumf_plan_info(const cumf_plan_t* plan, long info[4]);
+
+/*
+ * Fused half-iteration over the planned rows: RHS + Gram + solve in one pass,
+ * Gram never written to HBM.  Replaces, for one batch:
+ *   cusparseScsrmm2 + cublasSgeam            (als.cu:750-757 / 867-874)
+ *   get_hermitian100 / get_hermitianT10      (als.cu:788-817 / 900-924)
+ *   updateXWithCGHost | updateX/updateTheta  (als.cu:831,839 / 941,948)
+ * colidx/val: DEVICE CSR arrays of the whole matrix (indexed by the plan's row
+ * pointers); gather: DEVICE factors gathered from (cols x f); update: DEVICE
+ * factors being solved (rows x f), read as the CG warm start and overwritten.
+ */
+int cumf_als_update_fused(const cumf_plan_t* plan, const int* colidx, const float* val,
+                          const float* gather, float* update, int f, float lambda, int solver,
+                          int cg_iters, void* stream);
+
+/*
+ * Materialising Gram + RHS (the reference's data flow): tt receives
+ * (row_end-row_begin) x f x f fp32, row-major, both triangles, lambda*n_u on the
+ * diagonal -- exactly the `tt` / `xx` buffers of als.cu:782,897 -- and rhs (may be
+ * NULL) receives f-contiguous b_u at rhs[(u - row_begin) * f] (ythetaT, als.cu:756).
+ * With a slab-local CSC (hugewiki.cu:2332-2340) n_u is the slab-local count, so the
+ * partial Grams of several GPUs sum to the full system including lambda * n_u
+ * (hugewiki.cu:1187-1687, reduction at hugewiki.cu:2703-2730).
+ */
+int cumf_get_hermitian(const cumf_plan_t* plan, const int* colidx, const float* val,
+                       const float* gather, float* tt, float* rhs, int f, float lambda, void* stream);
+
+/* Batched CG on materialised systems; C alias of updateXWithCGHost (cg.h:30,
+ * cg.cu:682-686): A batch x f x f, x batch x f (warm start in, solution out),
+ * b batch x f, all DEVICE pointers.  Asynchronous on `stream`. */
+int cumf_cg_solve_batched(const float* A, float* x, const float* b, long batch, int f, int cg_iters,
+                          void* stream);
+
+/* Batched unpivoted LU + 1 RHS (cublasSgetrfBatched + cublasSgetrsBatched with
+ * PivotArray = NULL, als.cu:77,98 / 146,166).  A (batch x f x f) is NOT modified;
+ * x (batch x f) receives the solution; b batch x f. */
+int cumf_lu_solve_batched(const float* A, const float* b, float* x, long batch, int f, void* stream);
+
+/*
+ * Sum of squared errors over `count` ratings (RMSE kernel + cublasSasum,
+ * als.cu:191-219, 979-991, 1006-1019): sse_out is one DEVICE double.
+ * surpass_nan reproduces `#define SURPASS_NAN` (als.cu:201-211).
+ */
+int cumf_sse(const float* val, const int* row, const int* col, const float* thetaT, const float* XT,
+             long count, int f, int surpass_nan, double* sse_out, void* stream);
+
+/* Library/version probe used by the loaders' "fail loudly" checks. */
+int cumf_als_version(void);
+const char* cumf_als_arch(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUMF_ALS_CAPI_H_ */
