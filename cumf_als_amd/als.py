@@ -217,6 +217,17 @@ def sse(val, row, col, thetaT, XT, count: int | None = None, surpass_nan: bool =
     return out
 
 
+def set_kernel_timing(enable: bool) -> None:
+    _libmod.check(_libmod.load().cumf_set_kernel_timing(int(bool(enable))), "cumf_set_kernel_timing")
+
+
+def last_kernel_ms():
+    """(item_kernel_ms, reduce_kernel_ms) of the last half-iteration (HIP events on its stream)."""
+    a, b = C.c_float(), C.c_float()
+    _libmod.check(_libmod.load().cumf_last_kernel_ms(C.byref(a), C.byref(b)), "cumf_last_kernel_ms")
+    return a.value, b.value
+
+
 class ALSEngine:
     """A dataset resident in HBM + the two half-iteration plans (single GPU).
 

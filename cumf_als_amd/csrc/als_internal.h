@@ -50,6 +50,8 @@ struct KernelArgs {
 hipError_t launch_half_iteration(const KernelArgs& a, int mode, long n_items, long n_mrows, hipStream_t stream);
 hipError_t launch_solve_batched(const float* A, const float* b, float* x, long batch, int f, int mode, int cg_iters,
                                 hipStream_t stream);
+void set_kernel_timing(bool on);
+hipError_t last_kernel_ms(float* item_ms, float* reduce_ms);
 hipError_t launch_sse(const float* val, const int* row, const int* col, const float* thetaT, const float* XT,
                       long count, int f, int surpass_nan, double* out, hipStream_t stream);
 

@@ -621,6 +621,28 @@ __global__ __launch_bounds__(kThreads) void sse_kernel(const float* __restrict__
 // ----------------------------------------------------------------------------------
 // Launchers
 // ----------------------------------------------------------------------------------
+
+// Optional per-kernel HIP-event timing of the last half-iteration (bench.py's roofline
+// leg): events are recorded on the SAME stream the kernels are launched on.
+static bool g_timing = false;
+static hipEvent_t g_ev[3] = {nullptr, nullptr, nullptr};
+static bool g_timed_item = false, g_timed_reduce = false;
+
+void set_kernel_timing(bool on) {
+  g_timing = on;
+  if (on && g_ev[0] == nullptr)
+    for (auto& e : g_ev) (void)hipEventCreate(&e);
+}
+hipError_t last_kernel_ms(float* item_ms, float* reduce_ms) {
+  *item_ms = 0.f;
+  *reduce_ms = 0.f;
+  if (!g_ev[0]) return hipSuccess;
+  hipError_t e = hipEventSynchronize(g_ev[2]);
+  if (e != hipSuccess) return e;
+  if (g_timed_item) (void)hipEventElapsedTime(item_ms, g_ev[0], g_ev[1]);
+  if (g_timed_reduce) (void)hipEventElapsedTime(reduce_ms, g_ev[1], g_ev[2]);
+  return hipSuccess;
+}
 template <int NB, typename VT, int MODE>
 static hipError_t launch_nb(const KernelArgs& a, long n_items, long n_mrows, hipStream_t stream) {
   const size_t stage_floats = 2 * (size_t)kStage * Geo<NB>::LD;
@@ -639,17 +661,22 @@ static hipError_t launch_nb(const KernelArgs& a, long n_items, long n_mrows, hip
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
+  if (g_timing) (void)hipEventRecord(g_ev[0], stream);
+  g_timed_item = n_items > 0;
+  g_timed_reduce = n_mrows > 0;
   if (n_items > 0) {
     hipLaunchKernelGGL((als_item_kernel<NB, VT, MODE>), dim3((unsigned)n_items), dim3(kThreads), lds, stream, a);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
+  if (g_timing) (void)hipEventRecord(g_ev[1], stream);
   if (n_mrows > 0) {
     const size_t lds2 = (MODE == kModeMaterialize) ? 0 : lds;
     hipLaunchKernelGGL((als_reduce_kernel<NB, MODE>), dim3((unsigned)n_mrows), dim3(kThreads), lds2, stream, a);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
+  if (g_timing) (void)hipEventRecord(g_ev[2], stream);
   return hipSuccess;
 }
 

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -254,13 +255,24 @@ extern "C" int cumf_sse(const float* val, const int* row, const int* col, const 
   return 0;
 }
 
+extern "C" int cumf_set_kernel_timing(int enable) {
+  set_kernel_timing(enable != 0);
+  return 0;
+}
+
+extern "C" int cumf_last_kernel_ms(float* item_kernel_ms, float* reduce_kernel_ms) {
+  if (!item_kernel_ms || !reduce_kernel_ms) return (int)hipErrorInvalidValue;
+  CUMF_HIP_CHECK(last_kernel_ms(item_kernel_ms, reduce_kernel_ms));
+  return 0;
+}
+
 extern "C" int cumf_als_version(void) { return 100; }
 extern "C" const char* cumf_als_arch(void) { return "gfx950"; }
 
 // C++-linkage drop-in of the reference's inner solver API (cg.h:30, cg.cu:682-686):
 // device pointers, synchronous, aborts on error like cudaCheckError (als.h:667-674).
 void updateXWithCGHost(float* A, float* x, float* b, const int batchSize, const int f, const float cgIter) {
-  int rc = cumf_cg_solve_batched(A, x, b, batchSize, f, (int)cgIter, nullptr);
+  int rc = cumf_cg_solve_batched(A, x, b, batchSize, f, (int)ceilf(cgIter), nullptr);
   hipError_t e = hipDeviceSynchronize();
   if (rc != 0 || e != hipSuccess) {
     fprintf(stderr, "updateXWithCGHost failed: %s\n", hipGetErrorString(rc ? (hipError_t)rc : e));

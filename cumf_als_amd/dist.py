@@ -1,0 +1,282 @@
+"""Multi-GPU ALS: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI).
+
+Replaces the reference's 4-GPU program `hugewiki/hugewiki.cu` (OpenMP thread per GPU,
+`cudaMemcpy` peer copies into a staging buffer + `cublasSaxpy` on GPU 0, serial over
+GPUs: hugewiki.cu:2703-2730; LU on GPU 0 only; three broadcasts of Theta:
+hugewiki.cu:2744-2745; X round-tripping through host memory: hugewiki.cu:2571,2641).
+
+Two partitionings, both with contiguous nnz-balanced row slabs fixed for the run:
+
+* ``"gather"`` -- both factor matrices fit one GPU (Netflix on 288 GB).  Every rank
+  holds full replicas of X and Theta, solves its slab of rows with the fused kernel and
+  the slabs are exchanged with ONE all-gather per half-iteration.  No Gram leaves a GPU.
+* ``"reduce"`` -- the hugewiki scheme: X is row-sharded and stays device-resident
+  (hugewiki.cu:2273-2275 `csc_m[]` slabs), Theta is replicated.  update-X needs no
+  communication.  update-Theta: each rank forms the PARTIAL Gram/RHS of every Theta row
+  over its own X slab (slab-local CSC, lambda * n_local on the diagonal so that the
+  partials sum to the full system: hugewiki.cu:1187-1687), one reduce-scatter sums them
+  and leaves each rank 1/G of the systems, which it solves; one all-gather returns Theta.
+  Bytes per GPU: (G-1)/G * batch*f*f*4 instead of the reference's serial (G-1) full copies
+  into GPU 0.
+
+Compute is injected through an "ops" object so that the partition + collective logic
+can be exercised on CPU (gloo, world_size 2) with a stand-in; the product ops are
+`HipOps` (libALS.so kernels), and nothing else is ever used outside tests.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+# ----------------------------------------------------------------------------------------
+# partitioning (pure functions of the row pointers; covered by CPU tests)
+# ----------------------------------------------------------------------------------------
+
+def balanced_slabs(rowptr: np.ndarray, parts: int) -> np.ndarray:
+    """Cut rows [0, R) into `parts` contiguous slabs of (nearly) equal nnz.
+
+    Returns `parts + 1` boundaries.  Replaces the hand-written `csc_m[]` /
+    dynamic batch queue of hugewiki.cu:2273-2275, 2490-2496 with a static split.
+    """
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    rows = len(rowptr) - 1
+    total = rowptr[-1] - rowptr[0]
+    targets = rowptr[0] + (total * np.arange(1, parts, dtype=np.float64) / parts)
+    cuts = np.searchsorted(rowptr, targets, side="left")
+    bounds = np.concatenate([[0], np.clip(cuts, 0, rows), [rows]]).astype(np.int64)
+    return np.maximum.accumulate(bounds)
+
+
+def slice_csr(rowptr, colidx, val, r0: int, r1: int):
+    """Rows [r0, r1) of a CSR matrix with the row pointer rebased to 0
+    (the reference does this per batch with `zeroIndex`, hugewiki.cu:390-395, 2511)."""
+    s, e = int(rowptr[r0]), int(rowptr[r1])
+    return (rowptr[r0:r1 + 1] - rowptr[r0]), colidx[s:e], val[s:e]
+
+
+def local_csc_of_slab(rowptr_l, colidx_l, val_l, n_cols: int):
+    """CSC (as CSR of the transpose) of a row slab, with slab-LOCAL row ids -- the
+    per-GPU `R_train_csc.*.bin{g}` files of hugewiki.cu:2332-2340, built here instead of
+    pre-split on disk.  Inputs are numpy arrays of the rebased slab CSR."""
+    rows = len(rowptr_l) - 1
+    counts = np.diff(rowptr_l)
+    row_of = np.repeat(np.arange(rows, dtype=np.int64), counts)
+    order = np.argsort(colidx_l.astype(np.int64) * rows + row_of, kind="stable")
+    colptr = np.zeros(n_cols + 1, dtype=np.int64)
+    np.cumsum(np.bincount(colidx_l, minlength=n_cols), out=colptr[1:])
+    return colptr.astype(rowptr_l.dtype), row_of[order].astype(np.int32), val_l[order]
+
+
+# ----------------------------------------------------------------------------------------
+# compute ops (product = HIP kernels through the C ABI)
+# ----------------------------------------------------------------------------------------
+
+class HipOps:
+    """Compute ops backed by libALS.so on the current CUDA device."""
+
+    def __init__(self, device):
+        from . import als
+
+        self.als = als
+        self.device = torch.device(device)
+
+    def to_device(self, a: np.ndarray) -> torch.Tensor:
+        return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+
+    def plan(self, rowptr: np.ndarray, f: int, chunk: int = 0, row_begin: int = 0, row_end=None):
+        return self.als.Plan(np.ascontiguousarray(rowptr), f, row_begin, row_end, chunk)
+
+    def update_fused(self, plan, colidx, val, gather, update, lam, solver, cg_iters):
+        self.als.update_fused(plan, colidx, val, gather, update, lam, solver, cg_iters)
+
+    def get_hermitian(self, plan, colidx, val, gather, lam, tt, rhs):
+        self.als.get_hermitian(plan, colidx, val, gather, lam, tt, rhs)
+
+    def solve(self, tt, rhs, x, solver, cg_iters):
+        if solver in ("cg", 0):
+            self.als.cg_solve(tt, x, rhs, cg_iters)
+        else:
+            self.als.lu_solve(tt, rhs, x)
+
+
+# ----------------------------------------------------------------------------------------
+# collectives: on device tensors with nccl (RCCL), staged through the host with gloo
+# ----------------------------------------------------------------------------------------
+
+def _needs_host_staging(t: torch.Tensor) -> bool:
+    return t.is_cuda and dist.get_backend() != "nccl"
+
+
+def all_gather_rows(out: torch.Tensor, mine: torch.Tensor, bounds, group=None) -> None:
+    """out[bounds[g]:bounds[g+1]] <- rank g's `mine`, for all g (row slabs of unequal size).
+
+    One `all_gather_into_tensor` on slabs padded to the largest slab (a single RCCL
+    collective; on the fully connected xGMI mesh every link carries 1/(G-1) of it)."""
+    world = dist.get_world_size(group)
+    sizes = [int(bounds[g + 1] - bounds[g]) for g in range(world)]
+    mx = max(sizes) if sizes else 0
+    cols = out.shape[1]
+    stage_dev = torch.device("cpu") if _needs_host_staging(out) else out.device
+    send = torch.zeros((mx, cols), dtype=out.dtype, device=stage_dev)
+    send[: mine.shape[0]].copy_(mine)
+    recv = torch.empty((world * mx, cols), dtype=out.dtype, device=stage_dev)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    for g in range(world):
+        out[int(bounds[g]):int(bounds[g + 1])].copy_(recv[g * mx: g * mx + sizes[g]])
+
+
+def reduce_scatter_rows(full: torch.Tensor, group=None) -> torch.Tensor:
+    """Sum `full` ([world * k, ...]) over ranks and return this rank's k rows."""
+    world = dist.get_world_size(group)
+    k = full.shape[0] // world
+    if _needs_host_staging(full) or not full.is_cuda:
+        # gloo has no reduce_scatter: all_reduce + slice (test path only)
+        buf = full.cpu() if full.is_cuda else full.clone()
+        dist.all_reduce(buf, group=group)
+        r = dist.get_rank(group)
+        return buf[r * k:(r + 1) * k].to(full.device)
+    out = torch.empty((k,) + tuple(full.shape[1:]), dtype=full.dtype, device=full.device)
+    dist.reduce_scatter_tensor(out, full, group=group)
+    return out
+
+
+def all_gather_equal(out: torch.Tensor, mine: torch.Tensor, group=None) -> None:
+    if _needs_host_staging(out):
+        recv = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(recv, mine.cpu(), group=group)
+        out.copy_(recv)
+    else:
+        dist.all_gather_into_tensor(out, mine.contiguous(), group=group)
+
+
+# ----------------------------------------------------------------------------------------
+# the distributed engine
+# ----------------------------------------------------------------------------------------
+
+@dataclass
+class HostMatrix:
+    """Train matrix on the host: CSR over rows (m x n) and CSC over columns."""
+    m: int
+    n: int
+    csr_indptr: np.ndarray
+    csr_indices: np.ndarray
+    csr_data: np.ndarray
+    csc_indptr: np.ndarray
+    csc_indices: np.ndarray
+    csc_data: np.ndarray
+
+
+class DistALS:
+    """ALS over `world` ranks.  Every rank constructs it with the same host matrix (or, for
+    `scheme="reduce"`, at least its own row slab -- see `from_local_slab`)."""
+
+    def __init__(self, mat: HostMatrix, f: int, lam: float, ops, solver="cg", cg_iters: int = 6,
+                 scheme: str = "gather", theta_batch: int = 1, group=None, chunk: int = 0):
+        self.f, self.lam, self.ops = f, float(lam), ops
+        self.solver, self.cg_iters, self.scheme = solver, cg_iters, scheme
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.m, self.n = mat.m, mat.n
+        self.theta_batch = theta_batch
+        dev = ops.to_device(np.zeros(1, np.float32)).device
+        self.thetaT = torch.zeros((self.n, f), dtype=torch.float32, device=dev)
+
+        # X side: contiguous nnz-balanced row slabs
+        self.xb = balanced_slabs(mat.csr_indptr, self.world)
+        x0, x1 = int(self.xb[self.rank]), int(self.xb[self.rank + 1])
+        rp, ci, va = slice_csr(mat.csr_indptr, mat.csr_indices, mat.csr_data, x0, x1)
+        self.x_rows = x1 - x0
+        self.x_plan = ops.plan(rp, f, chunk)
+        self.x_colidx, self.x_val = ops.to_device(ci), ops.to_device(va)
+
+        if scheme == "gather":
+            self.XT = torch.zeros((self.m, f), dtype=torch.float32, device=dev)
+            self.tb = balanced_slabs(mat.csc_indptr, self.world)
+            t0, t1 = int(self.tb[self.rank]), int(self.tb[self.rank + 1])
+            rp, ci, va = slice_csr(mat.csc_indptr, mat.csc_indices, mat.csc_data, t0, t1)
+            self.t_rows = t1 - t0
+            self.t_plan = ops.plan(rp, f, chunk)
+            self.t_colidx, self.t_val = ops.to_device(ci), ops.to_device(va)
+        elif scheme == "reduce":
+            # X slab only (device-resident for the whole run); slab-local CSC for the partial Grams
+            self.XT = torch.zeros((self.x_rows, f), dtype=torch.float32, device=dev)
+            cp, ri, cv = local_csc_of_slab(np.asarray(rp), np.asarray(ci), np.asarray(va), self.n)
+            self.lc_rowidx, self.lc_val = ops.to_device(ri), ops.to_device(cv)
+            # Theta batches (als.cu:881-890), each padded to a multiple of world for the reduce-scatter
+            self.t_batches = []
+            for b in range(theta_batch):
+                size = self.n // theta_batch if b != theta_batch - 1 else self.n - b * (self.n // theta_batch)
+                off = b * (self.n // theta_batch)
+                self.t_batches.append((off, size, ops.plan(cp, f, chunk, off, off + size)))
+        else:
+            raise ValueError(scheme)
+
+    # -- factors ---------------------------------------------------------------------------
+    def init_factors(self, thetaT: np.ndarray, XT: np.ndarray | None = None) -> None:
+        self.thetaT.copy_(torch.from_numpy(np.ascontiguousarray(thetaT, np.float32)).reshape(self.n, self.f))
+        if XT is None:
+            self.XT.zero_()
+        else:
+            XT = np.ascontiguousarray(XT, np.float32).reshape(self.m, self.f)
+            if self.scheme == "reduce":
+                XT = XT[int(self.xb[self.rank]):int(self.xb[self.rank + 1])]
+            self.XT.copy_(torch.from_numpy(XT))
+
+    def full_XT(self) -> torch.Tensor:
+        """X on every rank (gathers the slabs in the "reduce" scheme)."""
+        if self.scheme == "gather":
+            return self.XT
+        out = torch.empty((self.m, self.f), dtype=torch.float32, device=self.XT.device)
+        all_gather_rows(out, self.XT, self.xb, self.group)
+        return out
+
+    # -- half-iterations -------------------------------------------------------------------
+    def update_x(self) -> None:
+        if self.scheme == "gather":
+            x0, x1 = int(self.xb[self.rank]), int(self.xb[self.rank + 1])
+            mine = self.XT[x0:x1]
+            self.ops.update_fused(self.x_plan, self.x_colidx, self.x_val, self.thetaT, mine, self.lam,
+                                  self.solver, self.cg_iters)
+            all_gather_rows(self.XT, mine, self.xb, self.group)
+        else:
+            self.ops.update_fused(self.x_plan, self.x_colidx, self.x_val, self.thetaT, self.XT, self.lam,
+                                  self.solver, self.cg_iters)
+
+    def update_theta(self) -> None:
+        if self.scheme == "gather":
+            t0, t1 = int(self.tb[self.rank]), int(self.tb[self.rank + 1])
+            mine = self.thetaT[t0:t1]
+            self.ops.update_fused(self.t_plan, self.t_colidx, self.t_val, self.XT, mine, self.lam,
+                                  self.solver, self.cg_iters)
+            all_gather_rows(self.thetaT, mine, self.tb, self.group)
+            return
+        f, w = self.f, self.world
+        dev = self.XT.device
+        for (off, size, plan) in self.t_batches:
+            ridx, rval = self.lc_rowidx, self.lc_val
+            k = (size + w - 1) // w
+            tt = torch.zeros((w * k, f, f), dtype=torch.float32, device=dev)
+            rhs = torch.zeros((w * k, f), dtype=torch.float32, device=dev)
+            # partial Gram / RHS over this rank's X slab (hugewiki.cu:2668-2679)
+            self.ops.get_hermitian(plan, ridx, rval, self.XT, self.lam, tt[:size], rhs[:size])
+            my_tt = reduce_scatter_rows(tt, self.group)      # replaces hugewiki.cu:2703-2717
+            my_rhs = reduce_scatter_rows(rhs, self.group)    # replaces hugewiki.cu:2719-2730
+            lo = min(self.rank * k, size)
+            hi = min((self.rank + 1) * k, size)
+            x = torch.zeros((k, f), dtype=torch.float32, device=dev)
+            if hi > lo:
+                x[: hi - lo].copy_(self.thetaT[off + lo: off + hi])          # CG warm start
+                self.ops.solve(my_tt[: hi - lo], my_rhs[: hi - lo], x[: hi - lo], self.solver, self.cg_iters)
+            gathered = torch.empty((w * k, f), dtype=torch.float32, device=dev)
+            all_gather_equal(gathered, x, self.group)        # replaces hugewiki.cu:2744-2745
+            self.thetaT[off: off + size].copy_(gathered[:size])
+
+    def iterate(self, iters: int = 1) -> None:
+        for _ in range(iters):
+            self.update_x()
+            self.update_theta()

@@ -114,6 +114,16 @@ int cumf_lu_solve_batched(const float* A, const float* b, float* x, long batch, 
 int cumf_sse(const float* val, const int* row, const int* col, const float* thetaT, const float* XT,
              long count, int f, int surpass_nan, double* sse_out, void* stream);
 
+/*
+ * Measurement hooks (no reference counterpart; the reference times phases with
+ * gettimeofday under #ifdef DEBUG, als.cu:728-732,821,845).  When enabled, the two
+ * kernels of a half-iteration (per-item Gram[+solve] kernel, chunked-row reduce kernel)
+ * are bracketed by HIP events recorded on the launch stream; cumf_last_kernel_ms waits
+ * for the last half-iteration and returns their durations in milliseconds.
+ */
+int cumf_set_kernel_timing(int enable);
+int cumf_last_kernel_ms(float* item_kernel_ms, float* reduce_kernel_ms);
+
 /* Library/version probe used by the loaders' "fail loudly" checks. */
 int cumf_als_version(void);
 const char* cumf_als_arch(void);

@@ -163,9 +163,12 @@ static void FN(lu_one)(REAL *As, REAL *bs, int f) {
     for (int j = 0; j < i; j++) acc = FN(fma_)(-As[i * f + j], bs[j], acc);
     bs[i] = acc;
   }
+  /* U x = y, column-oriented like the reference BLAS strsv that getrs performs
+   * (upper, no-transpose): x_j is final, then every y_i (i < j) loses U_ij x_j -- so
+   * row i accumulates its terms in DESCENDING j. */
   for (int i = f - 1; i >= 0; i--) {
     REAL acc = bs[i];
-    for (int j = i + 1; j < f; j++) acc = FN(fma_)(-As[i * f + j], bs[j], acc);
+    for (int j = f - 1; j > i; j--) acc = FN(fma_)(-As[i * f + j], bs[j], acc);
     bs[i] = acc / As[i * f + i];
   }
 }

@@ -150,33 +150,49 @@ def test_empty_row_gives_nan_like_reference(oracle, alslib):
         assert np.isfinite(xh[[0, 2]]).all()
 
 
-def test_sse_and_doals_rmse(oracle, alslib):
+@pytest.mark.parametrize("shape", [(400, 300, 40000, 3000, 20), (300, 200, 6000, 700, 20)])
+def test_sse_and_doals_rmse(oracle, alslib, shape):
+    """Full doALS (5 iterations) vs the oracle.  LU: factors bit-identical.  CG: RMSE
+    parity 1e-4 on the well-posed set; on the under-determined one (20 ratings per row at
+    f = 20) the truncated CG is chaotic at fp32 level, so the bound is the oracle's own
+    fp32-vs-fp64 spread."""
     _need_gpu()
     from cumf_als_amd import als
 
-    m, n, f, lam = 300, 200, 20, 0.05
-    r = _dataset(m, n, 6000, 700, seed=1)
+    m, n, nnz, nnz_test, f = shape
+    lam = 0.05
+    r = _dataset(m, n, nnz, nnz_test, seed=1)
     d = r.numpy()
     th0, x0 = oracle.init_factors(m, n, f)
+
+    def run(**kw):
+        return als.do_als(d["csr_indptr"], d["csr_indices"], d["csr_data"], d["csc_indices"], d["csc_indptr"],
+                          d["csc_data"], d["coo_row"], d["test_row"], d["test_col"], d["test_data"], m, n, f,
+                          r.nnz, r.nnz_test, lam, 5, kw.pop("xb", 1), kw.pop("tb", 1), 0, thetat_init=th0,
+                          xt_init=x0, return_log=True, **kw)
+
     for solver in ("cg", "lu"):
         th_o, x_o = th0.copy(), x0.copy()
         rm_o, log_o = oracle.do_als(d, th_o, x_o, m, n, f, lam, 5, solver=solver)
-        th, x, rm, log = als.do_als(d["csr_indptr"], d["csr_indices"], d["csr_data"], d["csc_indices"],
-                                    d["csc_indptr"], d["csc_data"], d["coo_row"], d["test_row"], d["test_col"],
-                                    d["test_data"], m, n, f, r.nnz, r.nnz_test, lam, 5, 1, 1, 0,
-                                    thetat_init=th0, xt_init=x0, solver=solver, return_log=True)
-        assert abs(rm - rm_o) <= 1e-4, (solver, rm, rm_o)
-        assert np.abs(log - log_o).max() <= 1e-4
+        th64, x64 = th0.copy(), x0.copy()
+        rm_64, log_64 = oracle.do_als(d, th64, x64, m, n, f, lam, 5, solver=solver, dtype=np.float64)
+        th, x, rm, log = run(solver=solver)
+        if solver == "lu":
+            np.testing.assert_array_equal(th, th_o)
+            np.testing.assert_array_equal(x, x_o)
+            assert np.abs(log - log_o).max() <= 2e-6
+        else:
+            floor = np.abs(log_64 - log_o).max()
+            tol = 1e-4 if nnz >= 40000 else max(1e-4, floor)
+            assert np.abs(log - log_o).max() <= tol, (np.abs(log - log_o).max(), floor)
+            assert abs(rm - rm_o) <= tol
         # batches change nothing (als.cu:768-777)
-        th2, x2, rm2 = als.do_als(d["csr_indptr"], d["csr_indices"], d["csr_data"], d["csc_indices"],
-                                  d["csc_indptr"], d["csc_data"], d["coo_row"], d["test_row"], d["test_col"],
-                                  d["test_data"], m, n, f, r.nnz, r.nnz_test, lam, 5, 3, 2, 0,
-                                  thetat_init=th0, xt_init=x0, solver=solver)
+        th2, x2, rm2, _ = run(solver=solver, xb=3, tb=2)
         np.testing.assert_array_equal(th2, th)
         np.testing.assert_array_equal(x2, x)
-        # unfused (reference data flow) agrees with fused
-        th3, x3, rm3 = als.do_als(d["csr_indptr"], d["csr_indices"], d["csr_data"], d["csc_indices"],
-                                  d["csc_indptr"], d["csc_data"], d["coo_row"], d["test_row"], d["test_col"],
-                                  d["test_data"], m, n, f, r.nnz, r.nnz_test, lam, 5, 1, 1, 0,
-                                  thetat_init=th0, xt_init=x0, solver=solver, fused=False)
-        assert abs(rm3 - rm) <= 1e-5
+        # unfused (reference data flow: Gram batch in HBM + separate solver) agrees with fused
+        th3, x3, rm3, _ = run(solver=solver, fused=False)
+        if solver == "lu":
+            np.testing.assert_array_equal(th3, th)
+        else:
+            assert abs(rm3 - rm) <= 1e-4
