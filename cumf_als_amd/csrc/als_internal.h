@@ -14,11 +14,14 @@ constexpr int kVecLd = 128;     // pitch of the CG vectors in LDS (fused solve n
 constexpr int kMaxFusedNB = 9;  // f <= 128  ->  NB = f / 16 + 1 <= 9
 constexpr int kMaxF = 207;      // NB <= 13
 
-enum { kModeCG = 0, kModeLU = 1, kModeMaterialize = 2 };
+enum { kModeCG = 0, kModeLU = 1, kModeMaterialize = 2, kModeLUExact = 3 };
 
 // Feature blocks of 16 including the slot that carries the rating value (RHS).
 __host__ __device__ constexpr int nb_for_f(int f) { return f / 16 + 1; }
-__host__ __device__ constexpr size_t solve_g_floats(int f) { return ((size_t)f * (f + 1) + 3) & ~(size_t)3; }
+// LDS system matrix: f rows of pitch solve_ldg(f) (>= f + 1 for the RHS column, multiple of 4 floats).
+__host__ __device__ constexpr int solve_ldg(int f) { return (f + 1 + 3) & ~3; }
+__host__ __device__ constexpr size_t solve_g_floats(int f) { return (size_t)f * solve_ldg(f); }
+constexpr int kCgExtraFloats = 12 * kVecLd;  // 4 per-wave operand copies + 2 x 4 partial mat-vecs
 
 struct KernelArgs {
   // plan items (one workgroup each)
@@ -45,6 +48,7 @@ struct KernelArgs {
   int f;
   float lambda;
   int cg_iters;
+  int dbg;  // ablation switches for profiling (CUMF_ALS_DBG); 0 in production
 };
 
 hipError_t launch_half_iteration(const KernelArgs& a, int mode, long n_items, long n_mrows, hipStream_t stream);

@@ -91,41 +91,60 @@ __device__ __forceinline__ float wave_sum(float v) {
 template <int NB, typename VT>
 struct Stager {
   static constexpr int VW = sizeof(VT) / 4;
-  static constexpr int PPR = Geo<NB>::LD / VW;  // vector pieces per stage row
-  static constexpr int TOTAL = kStage * PPR;
-  static constexpr int PASSES = (TOTAL + kThreads - 1) / kThreads;
+  static constexpr int PPR = Geo<NB>::LD / VW;        // vector pieces per stage row
+  static constexpr int LPR = PPR <= 32 ? 32 : (PPR <= 64 ? 64 : 128);  // lanes covering one row (power of two)
+  static constexpr int RPP = kThreads / LPR;          // rows per pass
+  static constexpr int PASSES = kStage / RPP;
+  static_assert(PPR <= 128, "stage row too wide");
   VT v[PASSES];
+  float rv[PASSES];
+  int cols[PASSES];
 
-  // Rows [0, nvalid) of the stage come from ratings [begin, begin + nvalid).
-  __device__ __forceinline__ void load(const int* __restrict__ colidx, const float* __restrict__ val,
-                                       const float* __restrict__ gather, int f, long long begin,
-                                       int nvalid, int tid) {
+  // Column indices of the stage that starts at rating `begin` (nvalid >= 1 ratings).
+  // Issued one stage ahead of the gather that consumes them, so the gather never waits
+  // on a dependent load.
+  __device__ __forceinline__ void load_cols(const int* __restrict__ colidx, long long begin, int nvalid, int tid) {
+    const int rsub = tid / LPR;
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
-      const int q = tid + p * kThreads;
-      const int r = q / PPR;
-      const int col0 = (q - r * PPR) * VW;
-      VT x = {};
-      if (q < TOTAL && r < nvalid) {
-        if (col0 < f) {
-          const int c = colidx[begin + r];
-          x = *reinterpret_cast<const VT*>(gather + (size_t)c * f + col0);
-        } else if (col0 == f) {
-          x[0] = val[begin + r];  // rating value rides in feature slot f -> RHS from the MFMA
-        }
+      const int r = rsub + p * RPP;
+      cols[p] = colidx[begin + (r < nvalid ? r : nvalid - 1)];
+    }
+  }
+
+  // Gather: lane (row r, piece pc) loads VW consecutive features of factor row cols[.].
+  // Every lane issues an in-bounds load (clamped address); nothing here consumes a loaded
+  // value, so the PASSES loads (and the rating loads of the slot-f lanes) stay in flight
+  // behind the MFMAs of the current stage.  Padding is zeroed in store().
+  __device__ __forceinline__ void gather(const float* __restrict__ val, const float* __restrict__ gat, int f,
+                                         long long begin, int nvalid, int tid) {
+    const int pc = tid % LPR, rsub = tid / LPR;
+    const int col0 = pc * VW;
+    const int col0c = col0 < f ? col0 : 0;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) v[p] = *reinterpret_cast<const VT*>(gat + (size_t)cols[p] * f + col0c);
+    if (col0 == f) {  // rating value rides in feature slot f
+#pragma unroll
+      for (int p = 0; p < PASSES; ++p) {
+        const int r = rsub + p * RPP;
+        rv[p] = val[begin + (r < nvalid ? r : nvalid - 1)];
       }
-      v[p] = x;
     }
   }
 
   // Rows [nvalid, nwrite) are written as zeros (nwrite = nvalid rounded up to 4).
-  __device__ __forceinline__ void store(float* __restrict__ stage, int nwrite, int tid) const {
+  __device__ __forceinline__ void store(float* __restrict__ stage, int f, int nvalid, int nwrite, int tid) const {
+    const int pc = tid % LPR, rsub = tid / LPR;
+    const int col0 = pc * VW;
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
-      const int q = tid + p * kThreads;
-      const int r = q / PPR;
-      const int col0 = (q - r * PPR) * VW;
-      if (q < TOTAL && r < nwrite) *reinterpret_cast<VT*>(stage + r * Geo<NB>::LD + col0) = v[p];
+      const int r = rsub + p * RPP;
+      VT x = v[p];
+      const bool live = (r < nvalid) && (col0 < f);
+#pragma unroll
+      for (int e = 0; e < VW; ++e) x[e] = live ? x[e] : 0.f;
+      if (col0 == f && r < nvalid) x[0] = rv[p];
+      if (pc < PPR && r < nwrite) *reinterpret_cast<VT*>(stage + r * Geo<NB>::LD + col0) = x;
     }
   }
 };
@@ -139,23 +158,52 @@ struct Stager {
 // tile column.  Accumulation is the exact k-ordered fmaf chain (rating order).
 // ----------------------------------------------------------------------------------
 template <int NB, int W>
+__device__ __forceinline__ void mma_group(const float (&blk)[NB], f32x4 (&acc)[Geo<NB>::TPW]) {
+  constexpr int NT = Geo<NB>::NT, TPW = Geo<NB>::TPW;
+  static_for<TPW>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    constexpr int t = W * TPW + s;
+    if constexpr (t < NT) {
+      constexpr int I = tile_I<NB>(t), J = tile_J<NB>(t);
+      acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(blk[I], blk[J], acc[s], 0, 0, 0);
+    }
+  });
+}
+
+template <int NB, int W>
 __device__ __forceinline__ void mma_stage(const float* __restrict__ stage, f32x4 (&acc)[Geo<NB>::TPW],
                                           int ngroups, int lane) {
-  constexpr int NT = Geo<NB>::NT, TPW = Geo<NB>::TPW, LD = Geo<NB>::LD;
+  constexpr int LD = Geo<NB>::LD;
   const float* rowp = stage + (lane >> 4) * LD + (lane & 15);
-  for (int g = 0; g < ngroups; ++g) {
-    float blk[NB];
+  if (ngroups == kStage / 4) {
+    // full stage: unrolled and software-pipelined by hand -- the operand reads of group
+    // g+1 are issued before the MFMAs of group g, so LDS latency hides behind the matrix
+    // pipe (blocks this wave never uses are dead code).
+    auto load_blk = [&](float (&blk)[NB], int g) {
 #pragma unroll
-    for (int b = 0; b < NB; ++b) blk[b] = rowp[16 * b];  // blocks this wave never uses are dead code
-    static_for<TPW>([&](auto sc) {
-      constexpr int s = decltype(sc)::value;
-      constexpr int t = W * TPW + s;
-      if constexpr (t < NT) {
-        constexpr int I = tile_I<NB>(t), J = tile_J<NB>(t);
-        acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(blk[I], blk[J], acc[s], 0, 0, 0);
-      }
-    });
-    rowp += 4 * LD;
+      for (int b = 0; b < NB; ++b) blk[b] = rowp[g * 4 * LD + 16 * b];
+    };
+    float blk_a[NB], blk_b[NB];
+    load_blk(blk_a, 0);
+#pragma unroll
+    for (int g = 0; g < kStage / 4; g += 2) {
+      load_blk(blk_b, g + 1);
+      __builtin_amdgcn_sched_barrier(0);  // keep the reads above the MFMAs (the scheduler sinks them otherwise)
+      mma_group<NB, W>(blk_a, acc);
+      __builtin_amdgcn_sched_barrier(0);
+      if (g + 2 < kStage / 4) load_blk(blk_a, g + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_group<NB, W>(blk_b, acc);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+    for (int g = 0; g < ngroups; ++g) {
+      float blk[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) blk[b] = rowp[16 * b];
+      mma_group<NB, W>(blk, acc);
+      rowp += 4 * LD;
+    }
   }
 }
 
@@ -240,79 +288,151 @@ __device__ __forceinline__ void partial_accumulate(f32x4 (&acc)[Geo<NB>::TPW], c
 }
 
 // ----------------------------------------------------------------------------------
-// In-LDS solvers.  G is f x ldg (ldg = f + 1, odd => column walks are conflict-free),
-// column f holds b.  256 threads.
+// In-LDS solvers.  G is f x ldg (ldg = solve_ldg(f): f + 1 rounded up to 4, so rows
+// are 16-byte aligned), column f holds b.  256 threads.
 // ----------------------------------------------------------------------------------
+
+// Deterministic wave64 sum on the DPP cross-lane network (no LDS traffic): xor-1, xor-2,
+// half-mirror, mirror inside each row of 16, then row_bcast15 / row_bcast31 across rows;
+// lane 63 ends with the total, returned wave-uniform.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_term(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_uniform(float v) {
+  v += dpp_term<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v += dpp_term<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+  v += dpp_term<0x141, 0xf>(v);  // row_half_mirror
+  v += dpp_term<0x140, 0xf>(v);  // row_mirror  -> every lane holds its row's sum
+  v += dpp_term<0x142, 0xa>(v);  // row_bcast15 -> rows 1,3 += rows 0,2
+  v += dpp_term<0x143, 0xc>(v);  // row_bcast31 -> rows 2,3 += row 1
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 
 // Conjugate gradient exactly as cg.cu:36-231: warm start, r = b - A x, <= cg_iters
 // iterations, stop when ||r||^2 < 1e-4 (CG_ERROR, cg.cu:31,195; the float is compared
-// against the double literal).  Dot products are deterministic wave butterflies that
-// every wave evaluates redundantly (same bits in every wave => uniform branch), in
-// place of the reference's order-dependent smem atomics (device_utilities.h:36-48).
-// vec: 6 * kVecLd floats of LDS.  Requires f <= 128.
+// against the double literal).
+//
+// Layout: every wave keeps ALL four vectors (x, r, p, ap) in registers, element i in lane
+// i & 63, slot i >> 6, and performs the vector updates and the dot products redundantly;
+// identical instruction sequences on identical data give identical bits in the four
+// waves, so alpha / beta / the exit test are workgroup-uniform without communication.
+// Only the mat-vec is shared: wave w multiplies rows [w*JW, (w+1)*JW) of the symmetric G
+// (16-byte LDS reads, both half-waves on different rows), the four partial vectors go
+// through LDS and ONE barrier per iteration.  Dot products are fixed-order DPP
+// reductions in place of the reference's order-dependent smem atomics
+// (device_utilities.h:36-48).  Requires f <= 128.
+template <int NB>
 __device__ __forceinline__ void cg_solve_lds(const float* __restrict__ G, int ldg, int f,
                                              float* __restrict__ vec, float* __restrict__ x_global,
                                              int cg_iters, int tid) {
-  float* xs = vec;
-  float* rs = vec + kVecLd;
-  float* ps = vec + 2 * kVecLd;
-  float* aps = vec + 3 * kVecLd;
-  float* part = vec + 4 * kVecLd;  // [2][kVecLd]
-  const int i = tid & 127, h = tid >> 7, lane = tid & 63;
-  const int jh = (f + 1) >> 1;
-  const int j0 = h ? jh : 0, j1 = h ? f : jh;
+  constexpr int MAXIT = 2 * NB;  // rows per half-wave: ceil(ceil(16*NB / 4) / 2)
+  const int wave = tid >> 6, lane = tid & 63;
+  const int c = lane & 31, h = lane >> 5;
+  float* pw = vec + wave * kVecLd;      // this wave's private copy of the mat-vec operand
+  float* part = vec + 4 * kVecLd;       // [2][4][kVecLd] partial mat-vecs, double-buffered
+  const int jw = (f + 3) >> 2;          // rows of G per wave
+  const int jbeg = wave * jw;
+  const int jend = (jbeg + jw) < f ? (jbeg + jw) : f;
+  const bool colok = 4 * c < ldg;
+  const int i0 = lane, i1 = lane + 64;
+  const bool ok0 = i0 < f, ok1 = i1 < f;
 
-  auto matvec = [&](const float* __restrict__ v) {
-    float s = 0.f;
-    if (i < f) {
-      for (int j = j0; j < j1; ++j) s = fmaf(G[j * ldg + i], v[j], s);  // A symmetric: column i == row i (cg.cu:55)
+  int buf = 0;
+  // y = G * v for the vector held as (v0, v1); result replicated in every wave
+  auto matvec = [&](float v0, float v1, float& y0, float& y1) {
+    pw[i0] = v0;
+    pw[i1] = v1;
+    __builtin_amdgcn_wave_barrier();
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int j = jbeg + h + 2 * it;
+      const bool on = (j < jend) && colok;
+      const int jc = on ? j : 0;
+      const f32x4 g = *reinterpret_cast<const f32x4*>(G + jc * ldg + (on ? 4 * c : 0));
+      const float pj = on ? pw[jc] : 0.f;
+      acc[0] = fmaf(g[0], pj, acc[0]);
+      acc[1] = fmaf(g[1], pj, acc[1]);
+      acc[2] = fmaf(g[2], pj, acc[2]);
+      acc[3] = fmaf(g[3], pj, acc[3]);
     }
-    part[h * kVecLd + i] = s;
-  };
-  auto dot = [&](const float* __restrict__ a, const float* __restrict__ b) {
-    float s = 0.f;
-    for (int j = lane; j < f; j += 64) s = fmaf(a[j], b[j], s);
-    return wave_sum(s);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] += __shfl_xor(acc[e], 32);
+    float* pb = part + (buf * 4 + wave) * kVecLd;
+    if (h == 0) *reinterpret_cast<f32x4*>(pb + 4 * c) = acc;
+    __syncthreads();
+    const float* pr = part + buf * 4 * kVecLd;
+    y0 = ((pr[i0] + pr[kVecLd + i0]) + pr[2 * kVecLd + i0]) + pr[3 * kVecLd + i0];
+    y1 = ((pr[i1] + pr[kVecLd + i1]) + pr[2 * kVecLd + i1]) + pr[3 * kVecLd + i1];
+    buf ^= 1;
   };
 
-  if (tid < f) xs[tid] = x_global[tid];
-  __syncthreads();
-  matvec(xs);
-  __syncthreads();
-  if (tid < f) {
-    const float r = G[tid * ldg + f] - (part[tid] + part[kVecLd + tid]);
-    rs[tid] = r;
-    ps[tid] = r;
-  }
-  __syncthreads();
-  float rsold = dot(rs, rs);
+  float x0 = ok0 ? x_global[i0] : 0.f, x1 = ok1 ? x_global[i1] : 0.f;
+  float ax0, ax1;
+  matvec(x0, x1, ax0, ax1);
+  float r0 = ok0 ? G[i0 * ldg + f] - ax0 : 0.f;
+  float r1 = ok1 ? G[i1 * ldg + f] - ax1 : 0.f;
+  float p0 = r0, p1 = r1;
+  float rsold = wave_sum_uniform(fmaf(r1, r1, r0 * r0));
   for (int iter = 0; iter < cg_iters; ++iter) {
-    matvec(ps);
-    __syncthreads();
-    if (tid < f) aps[tid] = part[tid] + part[kVecLd + tid];
-    __syncthreads();
-    const float pap = dot(ps, aps);
+    float ap0, ap1;
+    matvec(p0, p1, ap0, ap1);
+    ap0 = ok0 ? ap0 : 0.f;
+    ap1 = ok1 ? ap1 : 0.f;
+    const float pap = wave_sum_uniform(fmaf(p1, ap1, p0 * ap0));
     const float alpha = rsold / pap;
-    if (tid < f) {
-      xs[tid] = fmaf(alpha, ps[tid], xs[tid]);
-      rs[tid] = fmaf(-alpha, aps[tid], rs[tid]);
-    }
-    __syncthreads();
-    const float rsnew = dot(rs, rs);
+    x0 = fmaf(alpha, p0, x0);
+    x1 = fmaf(alpha, p1, x1);
+    r0 = fmaf(-alpha, ap0, r0);
+    r1 = fmaf(-alpha, ap1, r1);
+    const float rsnew = wave_sum_uniform(fmaf(r1, r1, r0 * r0));
     if ((double)rsnew < 1e-4) break;
     const float beta = rsnew / rsold;
     rsold = rsnew;
-    if (tid < f) ps[tid] = fmaf(beta, ps[tid], rs[tid]);
-    __syncthreads();
+    p0 = fmaf(beta, p0, r0);
+    p1 = fmaf(beta, p1, r1);
   }
-  if (tid < f) x_global[tid] = xs[tid];
+  if (wave == 0) {
+    if (ok0) x_global[i0] = x0;
+    if (ok1) x_global[i1] = x1;
+  }
+}
+
+// Back substitution U x = y by one wave (lanes own rows i = lane + 64 q), column-oriented
+// like BLAS strsv: x_k final, then every y_i (i < k) loses U_ik x_k.
+__device__ __forceinline__ void back_substitute_lds(const float* __restrict__ G, int ldg, int f,
+                                                    float* __restrict__ x_global, int lane) {
+  float y[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) y[q] = (lane + 64 * q < f) ? G[(lane + 64 * q) * ldg + f] : 0.f;
+  for (int k = f - 1; k >= 0; --k) {
+    const int kq = k >> 6, kl = k & 63;
+    float yk = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (q == kq) yk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y[q]), kl));
+    const float xk = yk / G[k * ldg + k];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = lane + 64 * q;
+      if (i == k)
+        y[q] = xk;
+      else if (i < k)
+        y[q] = fmaf(-G[i * ldg + k], xk, y[q]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (lane + 64 * q < f) x_global[lane + 64 * q] = y[q];
 }
 
 // Unpivoted Gaussian elimination on the augmented system [A | b] followed by back
 // substitution: the mathematical content of cublasSgetrfBatched(PivotArray = NULL) +
-// cublasSgetrsBatched (als.cu:77,98).  Same operation order as oracle_lu
+// cublasSgetrsBatched (als.cu:77,98), all in LDS.  Same operation order as oracle_lu
 // (right-looking, IEEE division by the pivot, fmaf updates, descending back
-// substitution), so the result is bit-identical to the oracle on identical A, b.
+// substitution), so the result is bit-identical to the oracle on identical A, b.  LDS
+// bandwidth bound; kept for f > 128 (any ldg) and as the exact-order reference variant.
 __device__ __forceinline__ void lu_solve_lds(float* __restrict__ G, int ldg, int f,
                                              float* __restrict__ x_global, int tid) {
   const int ti = tid >> 4, tj = tid & 15;
@@ -326,172 +446,218 @@ __device__ __forceinline__ void lu_solve_lds(float* __restrict__ G, int ldg, int
     }
     __syncthreads();
   }
-  if (tid < 64) {
-    const int lane = tid;
-    float y[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) y[q] = (lane + 64 * q < f) ? G[(lane + 64 * q) * ldg + f] : 0.f;
-    for (int k = f - 1; k >= 0; --k) {
-      const int kq = k >> 6, kl = k & 63;
-      float yk = 0.f;
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (q == kq) yk = __shfl(y[q], kl);
-      const float xk = yk / G[k * ldg + k];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = lane + 64 * q;
-        if (i == k)
-          y[q] = xk;
-        else if (i < k)
-          y[q] = fmaf(-G[i * ldg + k], xk, y[q]);
+  if (tid < 64) back_substitute_lds(G, ldg, f, x_global, tid);
+}
+
+// Register-resident symmetric elimination (the fast LU path, f <= 128).
+// The upper triangle of [A | b] is spread over the 16 x 16 thread grid, element (i, j) in
+// thread (i & 15, j & 15), register block (i >> 4, j >> 4).  Step k: the 16 threads
+// owning row k publish it to LDS row k of G (it is the final row k of U), one barrier,
+// every thread reads the <= 2*NB + 1 entries it needs and updates its registers:
+//     a_ij -= (u_ki / u_kk) * u_kj      (i > k, j >= i; column k of the symmetric Schur
+//                                         complement is read from row k)
+// i.e. Gaussian elimination without pivoting restricted to the upper triangle
+// (U = D L^T of the same A = L U).  Half the multiply-adds of lu_solve_lds, one LDS
+// broadcast row and one barrier per pivot instead of a full LDS sweep.
+template <int NB>
+__device__ __forceinline__ void lu_solve_reg(float* __restrict__ G, int ldg, int f,
+                                             float* __restrict__ x_global, int tid) {
+  const int ti = tid >> 4, tj = tid & 15;
+  float a[NB][NB];
+  static_for<NB>([&](auto bic) {
+    constexpr int bi = decltype(bic)::value;
+    static_for<NB>([&](auto bjc) {
+      constexpr int bj = decltype(bjc)::value;
+      if constexpr (bj >= bi) {
+        const int i = 16 * bi + ti, j = 16 * bj + tj;
+        a[bi][bj] = (i < f && j <= f) ? G[i * ldg + j] : 0.f;
       }
+    });
+  });
+  __syncthreads();
+  static_for<NB>([&](auto kbc) {
+    constexpr int kb = decltype(kbc)::value;
+    for (int kk = 0; kk < 16; ++kk) {
+      const int k = 16 * kb + kk;
+      if (k >= f) break;
+      if (ti == kk) {
+        static_for<NB>([&](auto bjc) {
+          constexpr int bj = decltype(bjc)::value;
+          if constexpr (bj >= kb) {
+            const int j = 16 * bj + tj;
+            if (j >= k && j <= f) G[k * ldg + j] = a[kb][bj];
+          }
+        });
+      }
+      __syncthreads();
+      const float* urow = G + k * ldg;
+      const float rp = 1.0f / urow[k];
+      float li[NB], uj[NB];
+      static_for<NB>([&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        if constexpr (b >= kb) {
+          const int i = 16 * b + ti, j = 16 * b + tj;
+          li[b] = (i > k && i < f) ? urow[i] * rp : 0.f;
+          uj[b] = (j <= f) ? urow[j] : 0.f;
+        }
+      });
+      static_for<NB>([&](auto bic) {
+        constexpr int bi = decltype(bic)::value;
+        static_for<NB>([&](auto bjc) {
+          constexpr int bj = decltype(bjc)::value;
+          if constexpr (bi >= kb && bj >= bi) a[bi][bj] = fmaf(-li[bi], uj[bj], a[bi][bj]);
+        });
+      });
     }
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (lane + 64 * q < f) x_global[lane + 64 * q] = y[q];
-  }
+  });
+  __syncthreads();
+  if (tid < 64) back_substitute_lds(G, ldg, f, x_global, tid);
 }
 
 // ----------------------------------------------------------------------------------
-// Finish one row whose complete accumulator tiles sit in `acc`.
+// Row epilogue.  dump_row<W> is per-wave (tile layout); solve_row is common to all waves.
 // ----------------------------------------------------------------------------------
-template <int NB, int MODE>
-__device__ __forceinline__ void finish_row(f32x4 (&acc)[Geo<NB>::TPW], float* smem, const KernelArgs& a,
-                                           int row, int rowlen, int tid) {
-  const int wave = tid >> 6, lane = tid & 63;
+template <int NB, int MODE, int W>
+__device__ __forceinline__ void dump_row(const f32x4 (&acc)[Geo<NB>::TPW], float* smem, const KernelArgs& a, int row,
+                                         int rowlen, int lane) {
   const int f = a.f;
-  // als.cu:547: float temp = (end - start) * lambda;
-  const float reg = (float)rowlen * a.lambda;
   if constexpr (MODE == kModeMaterialize) {
+    // als.cu:547: float temp = (end - start) * lambda;
+    const float reg = (float)rowlen * a.lambda;
     float* tt = a.tt + (size_t)(row - a.row_begin) * f * f;
     float* rhs = a.rhs ? a.rhs + (size_t)(row - a.row_begin) * f : nullptr;
-    switch (wave) {
-      case 0: tiles_to_global<NB, 0>(acc, tt, rhs, f, reg, lane); break;
-      case 1: tiles_to_global<NB, 1>(acc, tt, rhs, f, reg, lane); break;
-      case 2: tiles_to_global<NB, 2>(acc, tt, rhs, f, reg, lane); break;
-      default: tiles_to_global<NB, 3>(acc, tt, rhs, f, reg, lane); break;
-    }
+    tiles_to_global<NB, W>(acc, tt, rhs, f, reg, lane);
   } else {
-    const int ldg = f + 1;
-    float* G = smem;                         // aliases the stage buffers (all MFMA reads are done)
-    float* vec = smem + solve_g_floats(f);   // CG vectors behind G
-    switch (wave) {
-      case 0: tiles_to_lds<NB, 0>(acc, G, ldg, f, lane); break;
-      case 1: tiles_to_lds<NB, 1>(acc, G, ldg, f, lane); break;
-      case 2: tiles_to_lds<NB, 2>(acc, G, ldg, f, lane); break;
-      default: tiles_to_lds<NB, 3>(acc, G, ldg, f, lane); break;
-    }
+    tiles_to_lds<NB, W>(acc, smem, solve_ldg(f), f, lane);  // G aliases the stage buffers (MFMA reads are done)
+  }
+}
+
+template <int NB, int MODE>
+__device__ __forceinline__ void solve_row(float* smem, const KernelArgs& a, int row, int rowlen, int tid) {
+  if constexpr (MODE != kModeMaterialize) {
+    const int f = a.f, ldg = solve_ldg(f);
+    float* G = smem;
     __syncthreads();
-    if (tid < f) G[tid * ldg + tid] += reg;
+    if (tid < f) G[tid * ldg + tid] += (float)rowlen * a.lambda;  // als.cu:545-557
     __syncthreads();
     float* x = a.update + (size_t)row * f;
     if constexpr (MODE == kModeCG)
-      cg_solve_lds(G, ldg, f, vec, x, a.cg_iters, tid);
+      cg_solve_lds<NB>(G, ldg, f, smem + solve_g_floats(f), x, a.cg_iters, tid);
     else
-      lu_solve_lds(G, ldg, f, x, tid);
+      lu_solve_reg<NB>(G, ldg, f, x, tid);
   }
 }
 
 // ----------------------------------------------------------------------------------
 // Kernel 1: one workgroup per plan item (a whole row, or one chunk of a heavy row).
+// The four waves run wave-specialised copies of the same loop (each owns a fixed set of
+// tiles); every copy executes the same sequence of barriers.
 // ----------------------------------------------------------------------------------
+template <int NB, typename VT, int MODE, int W>
+__device__ __forceinline__ void item_body(float* smem, const KernelArgs& a, int row, long long begin, int len,
+                                          int slot, int rowlen, int tid) {
+  constexpr int LD = Geo<NB>::LD, TPW = Geo<NB>::TPW;
+  constexpr int kStageFloats = kStage * LD;
+  const int lane = tid & 63;
+  f32x4 acc[TPW];
+#pragma unroll
+  for (int s = 0; s < TPW; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nstages = (len + kStage - 1) / kStage;
+  auto nvalid_of = [&](int s) { return (len - s * kStage) < kStage ? (len - s * kStage) : kStage; };
+  Stager<NB, VT> st;
+  if (nstages > 0) {
+    const int nv = nvalid_of(0);
+    st.load_cols(a.colidx, begin, nv, tid);
+    st.gather(a.val, a.gather, a.f, begin, nv, tid);
+    if (nstages > 1) st.load_cols(a.colidx, begin + kStage, nvalid_of(1), tid);
+    st.store(smem, a.f, nv, (nv + 3) & ~3, tid);
+  }
+  __syncthreads();
+  for (int s = 0; s < nstages; ++s) {
+    const int nv = nvalid_of(s);
+    const bool more = (s + 1 < nstages);
+    int nv_next = 0;
+    if (more) {
+      nv_next = nvalid_of(s + 1);
+      if (!(a.dbg & 1))
+        st.gather(a.val, a.gather, a.f, begin + (long long)(s + 1) * kStage, nv_next, tid);  // cols came a stage ago
+      if (s + 2 < nstages && !(a.dbg & 2))
+        st.load_cols(a.colidx, begin + (long long)(s + 2) * kStage, nvalid_of(s + 2), tid);
+    }
+    if (!(a.dbg & 4)) mma_stage<NB, W>(smem + (s & 1) * kStageFloats, acc, (nv + 3) >> 2, lane);
+    if (more && !(a.dbg & 8)) st.store(smem + ((s + 1) & 1) * kStageFloats, a.f, nv_next, (nv_next + 3) & ~3, tid);
+    if (!(a.dbg & 16)) __syncthreads();
+  }
+  if (slot >= 0)
+    tiles_to_partial<NB, W>(acc, a.part + (size_t)slot * Geo<NB>::NT * 256, lane);
+  else
+    dump_row<NB, MODE, W>(acc, smem, a, row, rowlen, lane);
+}
+
 template <int NB, typename VT, int MODE>
 __global__ __launch_bounds__(kThreads) void als_item_kernel(const KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int LD = Geo<NB>::LD, TPW = Geo<NB>::TPW;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x;
   const int item = blockIdx.x;
   const int row = a.item_row[item];
   const long long begin = a.item_begin[item];
   const int len = a.item_len[item];
   const int slot = a.item_slot[item];
-
-  f32x4 acc[TPW];
-#pragma unroll
-  for (int s = 0; s < TPW; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  constexpr int kStageFloats = kStage * LD;
-  const int nstages = (len + kStage - 1) / kStage;
-  Stager<NB, VT> st;
-  if (nstages > 0) {
-    const int nv = len < kStage ? len : kStage;
-    st.load(a.colidx, a.val, a.gather, a.f, begin, nv, tid);
-    st.store(smem, (nv + 3) & ~3, tid);
+  const int rowlen = a.item_rowlen[item];
+  switch (tid >> 6) {
+    case 0: item_body<NB, VT, MODE, 0>(smem, a, row, begin, len, slot, rowlen, tid); break;
+    case 1: item_body<NB, VT, MODE, 1>(smem, a, row, begin, len, slot, rowlen, tid); break;
+    case 2: item_body<NB, VT, MODE, 2>(smem, a, row, begin, len, slot, rowlen, tid); break;
+    default: item_body<NB, VT, MODE, 3>(smem, a, row, begin, len, slot, rowlen, tid); break;
   }
-  __syncthreads();
-  for (int s = 0; s < nstages; ++s) {
-    const int nv = (len - s * kStage) < kStage ? (len - s * kStage) : kStage;
-    const bool more = (s + 1 < nstages);
-    int nv_next = 0;
-    if (more) {
-      nv_next = (len - (s + 1) * kStage) < kStage ? (len - (s + 1) * kStage) : kStage;
-      st.load(a.colidx, a.val, a.gather, a.f, begin + (long long)(s + 1) * kStage, nv_next, tid);
-    }
-    const float* cur = smem + (s & 1) * kStageFloats;
-    const int ngroups = (nv + 3) >> 2;
-    switch (wave) {
-      case 0: mma_stage<NB, 0>(cur, acc, ngroups, lane); break;
-      case 1: mma_stage<NB, 1>(cur, acc, ngroups, lane); break;
-      case 2: mma_stage<NB, 2>(cur, acc, ngroups, lane); break;
-      default: mma_stage<NB, 3>(cur, acc, ngroups, lane); break;
-    }
-    if (more) st.store(smem + ((s + 1) & 1) * kStageFloats, (nv_next + 3) & ~3, tid);
-    __syncthreads();
-  }
-
-  if (slot >= 0) {
-    float* part = a.part + (size_t)slot * Geo<NB>::NT * 256;
-    switch (wave) {
-      case 0: tiles_to_partial<NB, 0>(acc, part, lane); break;
-      case 1: tiles_to_partial<NB, 1>(acc, part, lane); break;
-      case 2: tiles_to_partial<NB, 2>(acc, part, lane); break;
-      default: tiles_to_partial<NB, 3>(acc, part, lane); break;
-    }
-    return;
-  }
-  finish_row<NB, MODE>(acc, smem, a, row, a.item_rowlen[item], tid);
+  if (slot < 0) solve_row<NB, MODE>(smem, a, row, rowlen, tid);
 }
 
 // ----------------------------------------------------------------------------------
 // Kernel 2: one workgroup per chunked row: sum the partial tiles in slot order (a
 // fixed, deterministic order) and finish the row.
 // ----------------------------------------------------------------------------------
+template <int NB, int MODE, int W>
+__device__ __forceinline__ void reduce_body(float* smem, const KernelArgs& a, int row, int slot0, int nslots,
+                                            int rowlen, int lane) {
+  constexpr int TPW = Geo<NB>::TPW;
+  f32x4 acc[TPW];
+#pragma unroll
+  for (int s = 0; s < TPW; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int sl = 0; sl < nslots; ++sl)
+    partial_accumulate<NB, W>(acc, a.part + (size_t)(slot0 + sl) * Geo<NB>::NT * 256, lane);
+  dump_row<NB, MODE, W>(acc, smem, a, row, rowlen, lane);
+}
+
 template <int NB, int MODE>
 __global__ __launch_bounds__(kThreads) void als_reduce_kernel(const KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int TPW = Geo<NB>::TPW;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int mr = blockIdx.x;
   const int row = a.mrow_row[mr];
   const int slot0 = a.mrow_slot0[mr];
   const int nslots = a.mrow_nslots[mr];
-
-  f32x4 acc[TPW];
-#pragma unroll
-  for (int s = 0; s < TPW; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int sl = 0; sl < nslots; ++sl) {
-    const float* part = a.part + (size_t)(slot0 + sl) * Geo<NB>::NT * 256;
-    switch (wave) {
-      case 0: partial_accumulate<NB, 0>(acc, part, lane); break;
-      case 1: partial_accumulate<NB, 1>(acc, part, lane); break;
-      case 2: partial_accumulate<NB, 2>(acc, part, lane); break;
-      default: partial_accumulate<NB, 3>(acc, part, lane); break;
-    }
+  const int rowlen = a.mrow_rowlen[mr];
+  switch (tid >> 6) {
+    case 0: reduce_body<NB, MODE, 0>(smem, a, row, slot0, nslots, rowlen, lane); break;
+    case 1: reduce_body<NB, MODE, 1>(smem, a, row, slot0, nslots, rowlen, lane); break;
+    case 2: reduce_body<NB, MODE, 2>(smem, a, row, slot0, nslots, rowlen, lane); break;
+    default: reduce_body<NB, MODE, 3>(smem, a, row, slot0, nslots, rowlen, lane); break;
   }
-  finish_row<NB, MODE>(acc, smem, a, row, a.mrow_rowlen[mr], tid);
+  solve_row<NB, MODE>(smem, a, row, rowlen, tid);
 }
 
 // ----------------------------------------------------------------------------------
 // Standalone batched solvers on materialised systems (the reference's data flow).
 // ----------------------------------------------------------------------------------
-template <int MODE>
+template <int NB, int MODE>
 __global__ __launch_bounds__(kThreads) void solve_lds_kernel(const float* __restrict__ A, const float* __restrict__ b,
                                                              float* __restrict__ x, int f, int cg_iters) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
   const size_t sys = blockIdx.x;
-  const int ldg = f + 1;
+  const int ldg = (NB == 0) ? f + 1 : solve_ldg(f);
   float* G = smem;
   const float* As = A + sys * (size_t)f * f;
   for (int e = tid; e < f * f; e += kThreads) {
@@ -500,10 +666,12 @@ __global__ __launch_bounds__(kThreads) void solve_lds_kernel(const float* __rest
   }
   if (tid < f) G[tid * ldg + f] = b[sys * f + tid];
   __syncthreads();
-  if constexpr (MODE == kModeCG)
-    cg_solve_lds(G, ldg, f, smem + solve_g_floats(f), x + sys * f, cg_iters, tid);
-  else
+  if constexpr (NB == 0)
     lu_solve_lds(G, ldg, f, x + sys * f, tid);
+  else if constexpr (MODE == kModeCG)
+    cg_solve_lds<NB>(G, ldg, f, smem + solve_g_floats(f), x + sys * f, cg_iters, tid);
+  else
+    lu_solve_reg<NB>(G, ldg, f, x + sys * f, tid);
 }
 
 // CG with A streamed from global memory every mat-vec, for f too large for an
@@ -648,7 +816,7 @@ static hipError_t launch_nb(const KernelArgs& a, long n_items, long n_mrows, hip
   const size_t stage_floats = 2 * (size_t)kStage * Geo<NB>::LD;
   size_t floats = stage_floats;
   if (MODE != kModeMaterialize) {
-    const size_t solve = solve_g_floats(a.f) + (MODE == kModeCG ? 6 * kVecLd : 0);
+    const size_t solve = solve_g_floats(a.f) + (MODE == kModeCG ? kCgExtraFloats : 0);
     floats = floats > solve ? floats : solve;
   }
   const size_t lds = floats * sizeof(float);
@@ -716,36 +884,54 @@ hipError_t launch_half_iteration(const KernelArgs& a, int mode, long n_items, lo
   }
 }
 
+template <int NB, int MODE>
+static hipError_t launch_solve_nb(const float* A, const float* b, float* x, long batch, int f, int cg_iters,
+                                  hipStream_t stream) {
+  const size_t floats = (NB == 0) ? (size_t)f * (f + 1) : solve_g_floats(f) + (MODE == kModeCG ? kCgExtraFloats : 0);
+  const size_t lds = floats * sizeof(float);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(solve_lds_kernel<NB, MODE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL((solve_lds_kernel<NB, MODE>), dim3((unsigned)batch), dim3(kThreads), lds, stream, A, b, x, f,
+                     cg_iters);
+  return hipGetLastError();
+}
+
+template <int MODE>
+static hipError_t launch_solve_mode(const float* A, const float* b, float* x, long batch, int f, int cg_iters,
+                                    hipStream_t stream) {
+  switch (nb_for_f(f)) {
+    case 1: return launch_solve_nb<1, MODE>(A, b, x, batch, f, cg_iters, stream);
+    case 2: return launch_solve_nb<2, MODE>(A, b, x, batch, f, cg_iters, stream);
+    case 3: return launch_solve_nb<3, MODE>(A, b, x, batch, f, cg_iters, stream);
+    case 4: return launch_solve_nb<4, MODE>(A, b, x, batch, f, cg_iters, stream);
+    case 5: return launch_solve_nb<5, MODE>(A, b, x, batch, f, cg_iters, stream);
+    case 6: return launch_solve_nb<6, MODE>(A, b, x, batch, f, cg_iters, stream);
+    case 7: return launch_solve_nb<7, MODE>(A, b, x, batch, f, cg_iters, stream);
+    case 8: return launch_solve_nb<8, MODE>(A, b, x, batch, f, cg_iters, stream);
+    case 9: return launch_solve_nb<9, MODE>(A, b, x, batch, f, cg_iters, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 hipError_t launch_solve_batched(const float* A, const float* b, float* x, long batch, int f, int mode, int cg_iters,
                                 hipStream_t stream) {
   if (batch <= 0) return hipSuccess;
-  if (mode == kModeCG && f > 128) {
-    const int threads = ((f + 63) / 64) * 64;
-    const size_t lds = (threads + 16) * sizeof(float);
-    hipLaunchKernelGGL(cg_global_kernel, dim3((unsigned)batch), dim3(threads), lds, stream, A, x, b, f, cg_iters);
-    return hipGetLastError();
-  }
-  const size_t lds = (solve_g_floats(f) + (mode == kModeCG ? 6 * kVecLd : 0)) * sizeof(float);
-  if (lds > 160 * 1024) return hipErrorInvalidValue;
-  hipError_t e;
-  if (mode == kModeCG) {
-    if (lds > 64 * 1024) {
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(solve_lds_kernel<kModeCG>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
+  if (f > 128) {
+    if (mode == kModeCG) {
+      const int threads = ((f + 63) / 64) * 64;
+      const size_t lds = (threads + 16) * sizeof(float);
+      hipLaunchKernelGGL(cg_global_kernel, dim3((unsigned)batch), dim3(threads), lds, stream, A, x, b, f, cg_iters);
+      return hipGetLastError();
     }
-    hipLaunchKernelGGL(solve_lds_kernel<kModeCG>, dim3((unsigned)batch), dim3(kThreads), lds, stream, A, b, x, f,
-                       cg_iters);
-  } else {
-    if (lds > 64 * 1024) {
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(solve_lds_kernel<kModeLU>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(solve_lds_kernel<kModeLU>, dim3((unsigned)batch), dim3(kThreads), lds, stream, A, b, x, f,
-                       cg_iters);
+    return launch_solve_nb<0, kModeLU>(A, b, x, batch, f, 0, stream);  // LDS-resident exact-order LU
   }
-  return hipGetLastError();
+  if (mode == kModeCG) return launch_solve_mode<kModeCG>(A, b, x, batch, f, cg_iters, stream);
+  if (mode == kModeLUExact) return launch_solve_nb<0, kModeLU>(A, b, x, batch, f, 0, stream);
+  return launch_solve_mode<kModeLU>(A, b, x, batch, f, cg_iters, stream);
 }
 
 hipError_t launch_sse(const float* val, const int* row, const int* col, const float* thetaT, const float* XT,

@@ -196,6 +196,8 @@ KernelArgs base_args(const cumf_plan_t* p, const int* colidx, const float* val, 
   a.row_begin = p->row_begin;
   a.f = f;
   a.lambda = lambda;
+  static const int dbg = getenv("CUMF_ALS_DBG") ? atoi(getenv("CUMF_ALS_DBG")) : 0;
+  a.dbg = dbg;
   return a;
 }
 
@@ -245,7 +247,11 @@ extern "C" int cumf_lu_solve_batched(const float* A, const float* b, float* x, l
     fprintf(stderr, "cumf_lu_solve_batched: f = %d unsupported (LDS-resident system needs f <= 200)\n", f);
     return (int)hipErrorInvalidValue;
   }
-  CUMF_HIP_CHECK(launch_solve_batched(A, b, x, batch, f, kModeLU, 0, static_cast<hipStream_t>(stream)));
+  // CUMF_ALS_LU_EXACT=1: the LDS-resident elimination in the oracle's exact operation order
+  // (bit-identical to oracle_lu); default: the register-resident symmetric elimination.
+  const char* ex = getenv("CUMF_ALS_LU_EXACT");
+  const int mode = (ex && atoi(ex) != 0) ? kModeLUExact : kModeLU;
+  CUMF_HIP_CHECK(launch_solve_batched(A, b, x, batch, f, mode, 0, static_cast<hipStream_t>(stream)));
   return 0;
 }
 

@@ -4,7 +4,8 @@ Tolerances (stated per north_star "within a stated fp32 tolerance"):
   * Gram of a whole (unchunked) row: BIT-EXACT vs the oracle -- the fp32 MFMA is a
     k-ordered fmaf chain, the same chain a reference thread evaluates (als.h:39-143).
   * Gram of a chunked row: partial chains are summed -> rel 2e-6 of the row's scale.
-  * LU solve on identical (A, b): bit-exact (same operation order as the oracle).
+  * LU solve on identical (A, b): the exact-order variant is bit-exact; the fast
+    register-resident symmetric elimination agrees to 2e-5 relative.
   * CG solve: dot products are reduced in a different (deterministic) order ->
     ||x - x_oracle||_inf <= 2e-4 * max(1, ||x||_inf); RMSE parity 1e-4.
 """
@@ -71,8 +72,11 @@ def test_gram_chunked_rows(oracle, alslib, f, chunk):
     assert np.abs(rhs.cpu().numpy() - b_o).max() <= 2e-6 * np.abs(b_o).max()
 
 
-@pytest.mark.parametrize("f", [10, 40, 100, 128])
-def test_lu_solve_bit_exact(oracle, alslib, f):
+@pytest.mark.parametrize("f", [10, 40, 100, 128, 200])
+def test_lu_solve(oracle, alslib, f, monkeypatch):
+    """Batched unpivoted LU.  CUMF_ALS_LU_EXACT=1 (LDS elimination in the oracle's operation
+    order; also what f > 128 uses): bit-exact.  Default (register-resident symmetric
+    elimination, l = u_ki * (1/u_kk)): same solution to 2e-5 relative."""
     _need_gpu()
     from cumf_als_amd import als
 
@@ -81,9 +85,17 @@ def test_lu_solve_bit_exact(oracle, alslib, f):
     theta = _factors(r.n, f, 3)
     A, b = oracle.gram_rhs(d["csr_indptr"], d["csr_indices"], d["csr_data"], theta, f, 0.05)
     x_o = oracle.lu(A, b, f)
-    x = als.lu_solve(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
+    Ag, bg = torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda()
+    monkeypatch.setenv("CUMF_ALS_LU_EXACT", "1")
+    x = als.lu_solve(Ag, bg)
     torch.cuda.synchronize()
     np.testing.assert_array_equal(x.cpu().numpy(), x_o)
+    monkeypatch.delenv("CUMF_ALS_LU_EXACT")
+    x = als.lu_solve(Ag, bg)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(Ag.cpu().numpy(), A)  # A is not modified
+    err = np.abs(x.cpu().numpy() - x_o).max()
+    assert err <= 2e-5 * np.abs(x_o).max(), err
 
 
 @pytest.mark.parametrize("f", [10, 40, 100, 128, 200])
@@ -178,9 +190,9 @@ def test_sse_and_doals_rmse(oracle, alslib, shape):
         rm_64, log_64 = oracle.do_als(d, th64, x64, m, n, f, lam, 5, solver=solver, dtype=np.float64)
         th, x, rm, log = run(solver=solver)
         if solver == "lu":
-            np.testing.assert_array_equal(th, th_o)
-            np.testing.assert_array_equal(x, x_o)
-            assert np.abs(log - log_o).max() <= 2e-6
+            assert np.abs(th - th_o).max() <= 1e-4 * np.abs(th_o).max()
+            assert np.abs(x - x_o).max() <= 1e-4 * np.abs(x_o).max()
+            assert np.abs(log - log_o).max() <= 1e-5
         else:
             floor = np.abs(log_64 - log_o).max()
             tol = 1e-4 if nnz >= 40000 else max(1e-4, floor)
@@ -192,7 +204,4 @@ def test_sse_and_doals_rmse(oracle, alslib, shape):
         np.testing.assert_array_equal(x2, x)
         # unfused (reference data flow: Gram batch in HBM + separate solver) agrees with fused
         th3, x3, rm3, _ = run(solver=solver, fused=False)
-        if solver == "lu":
-            np.testing.assert_array_equal(th3, th)
-        else:
-            assert abs(rm3 - rm) <= 1e-4
+        assert abs(rm3 - rm) <= (1e-5 if solver == "lu" else 1e-4)
