@@ -18,10 +18,17 @@ enum { kModeCG = 0, kModeLU = 1, kModeMaterialize = 2, kModeLUExact = 3 };
 
 // Feature blocks of 16 including the slot that carries the rating value (RHS).
 __host__ __device__ constexpr int nb_for_f(int f) { return f / 16 + 1; }
-// LDS system matrix: f rows of pitch solve_ldg(f) (>= f + 1 for the RHS column, multiple of 4 floats).
-__host__ __device__ constexpr int solve_ldg(int f) { return (f + 1 + 3) & ~3; }
-__host__ __device__ constexpr size_t solve_g_floats(int f) { return (size_t)f * solve_ldg(f); }
+// LDS system matrix G: f rows, column f = RHS.  CG reads rows with 16-byte loads (pitch a
+// multiple of 4 floats); the LU paths walk columns (odd pitch = conflict-free).
+__host__ __device__ constexpr int solve_ldg(int f, int mode) { return mode == kModeCG ? ((f + 1 + 3) & ~3) : (f + 1); }
+__host__ __device__ constexpr size_t solve_g_floats(int f, int mode) {
+  return ((size_t)f * solve_ldg(f, mode) + 3) & ~(size_t)3;
+}
 constexpr int kCgExtraFloats = 12 * kVecLd;  // 4 per-wave operand copies + 2 x 4 partial mat-vecs
+// whole LDS footprint of a solve: G + CG exchange buffers | G + pivot reciprocals (fast LU)
+__host__ __device__ constexpr size_t solve_lds_floats(int f, int mode) {
+  return solve_g_floats(f, mode) + (mode == kModeCG ? (size_t)kCgExtraFloats : (mode == kModeLU ? (size_t)kVecLd : 0));
+}
 
 struct KernelArgs {
   // plan items (one workgroup each)

@@ -175,43 +175,37 @@ __device__ __forceinline__ void mma_stage(const float* __restrict__ stage, f32x4
                                           int ngroups, int lane) {
   constexpr int LD = Geo<NB>::LD;
   const float* rowp = stage + (lane >> 4) * LD + (lane & 15);
-  if (ngroups == kStage / 4) {
-    // full stage: unrolled and software-pipelined by hand -- the operand reads of group
-    // g+1 are issued before the MFMAs of group g, so LDS latency hides behind the matrix
-    // pipe (blocks this wave never uses are dead code).
-    auto load_blk = [&](float (&blk)[NB], int g) {
+  // Software-pipelined by hand: the operand reads of group g+1 are issued before the MFMAs
+  // of group g so that LDS latency hides behind the matrix pipe (the scheduler sinks the
+  // reads next to their use otherwise, hence the sched_barriers).  Blocks this wave never
+  // uses are dead code.  The read-ahead may run up to two groups past `ngroups`: it stays
+  // inside the LDS allocation (launch_nb pads it) and the values are never used.
+  auto load_blk = [&](float (&blk)[NB], const float* p) {
 #pragma unroll
-      for (int b = 0; b < NB; ++b) blk[b] = rowp[g * 4 * LD + 16 * b];
-    };
-    float blk_a[NB], blk_b[NB];
-    load_blk(blk_a, 0);
-#pragma unroll
-    for (int g = 0; g < kStage / 4; g += 2) {
-      load_blk(blk_b, g + 1);
-      __builtin_amdgcn_sched_barrier(0);  // keep the reads above the MFMAs (the scheduler sinks them otherwise)
-      mma_group<NB, W>(blk_a, acc);
-      __builtin_amdgcn_sched_barrier(0);
-      if (g + 2 < kStage / 4) load_blk(blk_a, g + 2);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_group<NB, W>(blk_b, acc);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  } else {
-    for (int g = 0; g < ngroups; ++g) {
-      float blk[NB];
-#pragma unroll
-      for (int b = 0; b < NB; ++b) blk[b] = rowp[16 * b];
-      mma_group<NB, W>(blk, acc);
-      rowp += 4 * LD;
-    }
+    for (int b = 0; b < NB; ++b) blk[b] = p[16 * b];
+  };
+  float blk_a[NB], blk_b[NB];
+  load_blk(blk_a, rowp);
+  int g = 0;
+  for (; g + 1 < ngroups; g += 2) {
+    load_blk(blk_b, rowp + 4 * LD);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_group<NB, W>(blk_a, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    load_blk(blk_a, rowp + 8 * LD);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_group<NB, W>(blk_b, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    rowp += 8 * LD;
   }
+  if (g < ngroups) mma_group<NB, W>(blk_a, acc);
 }
 
 // Accumulator tile -> LDS system matrix G (f x ldg, column f = RHS).  C/D layout of
 // the 16x16 MFMA: lane l, register r holds D[4*(l>>4) + r][l & 15].
 template <int NB, int W>
 __device__ __forceinline__ void tiles_to_lds(const f32x4 (&acc)[Geo<NB>::TPW], float* __restrict__ G,
-                                             int ldg, int f, int lane) {
+                                             int ldg, int f, float reg, int lane) {
   constexpr int NT = Geo<NB>::NT, TPW = Geo<NB>::TPW;
   const int c = lane & 15, kk = lane >> 4;
   static_for<TPW>([&](auto sc) {
@@ -222,7 +216,8 @@ __device__ __forceinline__ void tiles_to_lds(const f32x4 (&acc)[Geo<NB>::TPW], f
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = 16 * I + 4 * kk + r, j = 16 * J + c;
-        const float v = acc[s][r];
+        float v = acc[s][r];
+        if (I == J && i == j) v += reg;                    // lambda * n_u on the diagonal (als.cu:545-557)
         if (i < f && j <= f) G[i * ldg + j] = v;           // j == f: b_i = sum r * theta[i]
         if (I != J && i < f && j < f) G[j * ldg + i] = v;  // mirror
       }
@@ -400,30 +395,51 @@ __device__ __forceinline__ void cg_solve_lds(const float* __restrict__ G, int ld
 }
 
 // Back substitution U x = y by one wave (lanes own rows i = lane + 64 q), column-oriented
-// like BLAS strsv: x_k final, then every y_i (i < k) loses U_ik x_k.
+// like BLAS strsv: x_k final, then every y_i (i < k) loses U_ik x_k.  rdiag (may be null)
+// holds the reciprocals of the pivots; without it x_k = y_k / U_kk (IEEE division).
+template <bool RECIP, int NQ>
 __device__ __forceinline__ void back_substitute_lds(const float* __restrict__ G, int ldg, int f,
+                                                    const float* __restrict__ rdiag,
                                                     float* __restrict__ x_global, int lane) {
-  float y[4];
+  float y[NQ];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) y[q] = (lane + 64 * q < f) ? G[(lane + 64 * q) * ldg + f] : 0.f;
+  for (int q = 0; q < NQ; ++q) y[q] = (lane + 64 * q < f) ? G[(lane + 64 * q) * ldg + f] : 0.f;
+  // column k of U for this lane's rows, fetched one step ahead of its use
+  float col[NQ], coln[NQ];
+  float dk = 0.f, dkn = 0.f;
+  const float* colp[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int i = lane + 64 * q;
+    colp[q] = G + (i < f ? i : f - 1) * ldg;
+  }
+  auto fetch = [&](int k, float (&cv)[NQ], float& d) {
+    const int kc = k < 0 ? 0 : k;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) cv[q] = colp[q][kc];
+    d = RECIP ? rdiag[kc] : G[kc * ldg + kc];
+  };
+  fetch(f - 1, col, dk);
   for (int k = f - 1; k >= 0; --k) {
+    fetch(k - 1, coln, dkn);
     const int kq = k >> 6, kl = k & 63;
     float yk = 0.f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < NQ; ++q)
       if (q == kq) yk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y[q]), kl));
-    const float xk = yk / G[k * ldg + k];
+    const float xk = RECIP ? yk * dk : yk / dk;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NQ; ++q) {
       const int i = lane + 64 * q;
-      if (i == k)
-        y[q] = xk;
-      else if (i < k)
-        y[q] = fmaf(-G[i * ldg + k], xk, y[q]);
+      const float upd = fmaf(-col[q], xk, y[q]);
+      y[q] = (i == k) ? xk : ((i < k) ? upd : y[q]);
     }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) col[q] = coln[q];
+    dk = dkn;
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
+  for (int q = 0; q < NQ; ++q)
     if (lane + 64 * q < f) x_global[lane + 64 * q] = y[q];
 }
 
@@ -446,7 +462,7 @@ __device__ __forceinline__ void lu_solve_lds(float* __restrict__ G, int ldg, int
     }
     __syncthreads();
   }
-  if (tid < 64) back_substitute_lds(G, ldg, f, x_global, tid);
+  if (tid < 64) back_substitute_lds<false, 4>(G, ldg, f, nullptr, x_global, tid);
 }
 
 // Register-resident symmetric elimination (the fast LU path, f <= 128).
@@ -460,7 +476,7 @@ __device__ __forceinline__ void lu_solve_lds(float* __restrict__ G, int ldg, int
 // (U = D L^T of the same A = L U).  Half the multiply-adds of lu_solve_lds, one LDS
 // broadcast row and one barrier per pivot instead of a full LDS sweep.
 template <int NB>
-__device__ __forceinline__ void lu_solve_reg(float* __restrict__ G, int ldg, int f,
+__device__ __forceinline__ void lu_solve_reg(float* __restrict__ G, int ldg, int f, float* __restrict__ rdiag,
                                              float* __restrict__ x_global, int tid) {
   const int ti = tid >> 4, tj = tid & 15;
   float a[NB][NB];
@@ -470,48 +486,65 @@ __device__ __forceinline__ void lu_solve_reg(float* __restrict__ G, int ldg, int
       constexpr int bj = decltype(bjc)::value;
       if constexpr (bj >= bi) {
         const int i = 16 * bi + ti, j = 16 * bj + tj;
-        a[bi][bj] = (i < f && j <= f) ? G[i * ldg + j] : 0.f;
+        const float v = G[(i < f ? i : f - 1) * ldg + (j <= f ? j : f)];
+        a[bi][bj] = (i < f && j <= f) ? v : 0.f;
       }
     });
   });
   __syncthreads();
+  // Rows >= f and columns > f of the register image are padding: they are never published
+  // and never read back, so the updates below run on them unmasked (whatever lands there
+  // is dead).  Row-k reads past column f stay inside the LDS allocation (G is followed by
+  // rdiag) and only feed those dead registers.
   static_for<NB>([&](auto kbc) {
     constexpr int kb = decltype(kbc)::value;
+    const float* urow_i = G + (16 * kb) * ldg + ti;  // + kk * ldg + 16 * b
+    const float* urow_j = G + (16 * kb) * ldg + tj;
     for (int kk = 0; kk < 16; ++kk) {
       const int k = 16 * kb + kk;
       if (k >= f) break;
-      if (ti == kk) {
+      if (ti == kk) {  // this thread row owns pivot row k: publish it (= final row k of U)
         static_for<NB>([&](auto bjc) {
           constexpr int bj = decltype(bjc)::value;
           if constexpr (bj >= kb) {
             const int j = 16 * bj + tj;
-            if (j >= k && j <= f) G[k * ldg + j] = a[kb][bj];
+            if (j <= f) G[k * ldg + j] = a[kb][bj];
           }
         });
       }
       __syncthreads();
-      const float* urow = G + k * ldg;
-      const float rp = 1.0f / urow[k];
-      float li[NB], uj[NB];
+      // all reads unconditional and issued together: one LDS latency per pivot
+      float ui[NB], uj[NB];
+      const float piv = G[k * ldg + k];
       static_for<NB>([&](auto bc) {
         constexpr int b = decltype(bc)::value;
         if constexpr (b >= kb) {
-          const int i = 16 * b + ti, j = 16 * b + tj;
-          li[b] = (i > k && i < f) ? urow[i] * rp : 0.f;
-          uj[b] = (j <= f) ? urow[j] : 0.f;
+          ui[b] = urow_i[16 * b];
+          uj[b] = urow_j[16 * b];
         }
+      });
+      float rp = __builtin_amdgcn_rcpf(piv);
+      rp = fmaf(fmaf(-piv, rp, 1.0f), rp, rp);  // one Newton step: 1/piv to ~1 ulp
+      if (tid == 0) rdiag[k] = rp;
+      float li[NB];
+      static_for<NB>([&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        if constexpr (b > kb) li[b] = -ui[b] * rp;
+        if constexpr (b == kb) li[b] = (ti > kk) ? -ui[b] * rp : 0.f;  // rows <= k of the pivot block are final
       });
       static_for<NB>([&](auto bic) {
         constexpr int bi = decltype(bic)::value;
         static_for<NB>([&](auto bjc) {
           constexpr int bj = decltype(bjc)::value;
-          if constexpr (bi >= kb && bj >= bi) a[bi][bj] = fmaf(-li[bi], uj[bj], a[bi][bj]);
+          if constexpr (bi >= kb && bj >= bi) a[bi][bj] = fmaf(li[bi], uj[bj], a[bi][bj]);
         });
       });
+      urow_i += ldg;
+      urow_j += ldg;
     }
   });
   __syncthreads();
-  if (tid < 64) back_substitute_lds(G, ldg, f, x_global, tid);
+  if (tid < 64) back_substitute_lds<true, (16 * NB + 63) / 64>(G, ldg, f, rdiag, x_global, tid);
 }
 
 // ----------------------------------------------------------------------------------
@@ -528,23 +561,22 @@ __device__ __forceinline__ void dump_row(const f32x4 (&acc)[Geo<NB>::TPW], float
     float* rhs = a.rhs ? a.rhs + (size_t)(row - a.row_begin) * f : nullptr;
     tiles_to_global<NB, W>(acc, tt, rhs, f, reg, lane);
   } else {
-    tiles_to_lds<NB, W>(acc, smem, solve_ldg(f), f, lane);  // G aliases the stage buffers (MFMA reads are done)
+    // G aliases the stage buffers (all MFMA reads are done)
+    tiles_to_lds<NB, W>(acc, smem, solve_ldg(f, MODE), f, (float)rowlen * a.lambda, lane);
   }
 }
 
 template <int NB, int MODE>
-__device__ __forceinline__ void solve_row(float* smem, const KernelArgs& a, int row, int rowlen, int tid) {
+__device__ __forceinline__ void solve_row(float* smem, const KernelArgs& a, int row, int tid) {
   if constexpr (MODE != kModeMaterialize) {
-    const int f = a.f, ldg = solve_ldg(f);
+    const int f = a.f, ldg = solve_ldg(f, MODE);
     float* G = smem;
-    __syncthreads();
-    if (tid < f) G[tid * ldg + tid] += (float)rowlen * a.lambda;  // als.cu:545-557
-    __syncthreads();
+    __syncthreads();  // all tiles are in G
     float* x = a.update + (size_t)row * f;
     if constexpr (MODE == kModeCG)
-      cg_solve_lds<NB>(G, ldg, f, smem + solve_g_floats(f), x, a.cg_iters, tid);
+      cg_solve_lds<NB>(G, ldg, f, smem + solve_g_floats(f, MODE), x, a.cg_iters, tid);
     else
-      lu_solve_reg<NB>(G, ldg, f, x, tid);
+      lu_solve_reg<NB>(G, ldg, f, smem + solve_g_floats(f, MODE), x, tid);
   }
 }
 
@@ -611,7 +643,7 @@ __global__ __launch_bounds__(kThreads) void als_item_kernel(const KernelArgs a) 
     case 2: item_body<NB, VT, MODE, 2>(smem, a, row, begin, len, slot, rowlen, tid); break;
     default: item_body<NB, VT, MODE, 3>(smem, a, row, begin, len, slot, rowlen, tid); break;
   }
-  if (slot < 0) solve_row<NB, MODE>(smem, a, row, rowlen, tid);
+  if (slot < 0) solve_row<NB, MODE>(smem, a, row, tid);
 }
 
 // ----------------------------------------------------------------------------------
@@ -645,7 +677,7 @@ __global__ __launch_bounds__(kThreads) void als_reduce_kernel(const KernelArgs a
     case 2: reduce_body<NB, MODE, 2>(smem, a, row, slot0, nslots, rowlen, lane); break;
     default: reduce_body<NB, MODE, 3>(smem, a, row, slot0, nslots, rowlen, lane); break;
   }
-  solve_row<NB, MODE>(smem, a, row, rowlen, tid);
+  solve_row<NB, MODE>(smem, a, row, tid);
 }
 
 // ----------------------------------------------------------------------------------
@@ -657,7 +689,7 @@ __global__ __launch_bounds__(kThreads) void solve_lds_kernel(const float* __rest
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
   const size_t sys = blockIdx.x;
-  const int ldg = (NB == 0) ? f + 1 : solve_ldg(f);
+  const int ldg = solve_ldg(f, MODE);
   float* G = smem;
   const float* As = A + sys * (size_t)f * f;
   for (int e = tid; e < f * f; e += kThreads) {
@@ -669,9 +701,9 @@ __global__ __launch_bounds__(kThreads) void solve_lds_kernel(const float* __rest
   if constexpr (NB == 0)
     lu_solve_lds(G, ldg, f, x + sys * f, tid);
   else if constexpr (MODE == kModeCG)
-    cg_solve_lds<NB>(G, ldg, f, smem + solve_g_floats(f), x + sys * f, cg_iters, tid);
+    cg_solve_lds<NB>(G, ldg, f, smem + solve_g_floats(f, MODE), x + sys * f, cg_iters, tid);
   else
-    lu_solve_reg<NB>(G, ldg, f, x + sys * f, tid);
+    lu_solve_reg<NB>(G, ldg, f, smem + solve_g_floats(f, MODE), x + sys * f, tid);
 }
 
 // CG with A streamed from global memory every mat-vec, for f too large for an
@@ -813,10 +845,10 @@ hipError_t last_kernel_ms(float* item_ms, float* reduce_ms) {
 }
 template <int NB, typename VT, int MODE>
 static hipError_t launch_nb(const KernelArgs& a, long n_items, long n_mrows, hipStream_t stream) {
-  const size_t stage_floats = 2 * (size_t)kStage * Geo<NB>::LD;
+  const size_t stage_floats = (2 * (size_t)kStage + 8) * Geo<NB>::LD;  // + read-ahead pad of mma_stage
   size_t floats = stage_floats;
   if (MODE != kModeMaterialize) {
-    const size_t solve = solve_g_floats(a.f) + (MODE == kModeCG ? kCgExtraFloats : 0);
+    const size_t solve = solve_lds_floats(a.f, MODE);
     floats = floats > solve ? floats : solve;
   }
   const size_t lds = floats * sizeof(float);
@@ -887,7 +919,7 @@ hipError_t launch_half_iteration(const KernelArgs& a, int mode, long n_items, lo
 template <int NB, int MODE>
 static hipError_t launch_solve_nb(const float* A, const float* b, float* x, long batch, int f, int cg_iters,
                                   hipStream_t stream) {
-  const size_t floats = (NB == 0) ? (size_t)f * (f + 1) : solve_g_floats(f) + (MODE == kModeCG ? kCgExtraFloats : 0);
+  const size_t floats = solve_lds_floats(f, NB == 0 ? kModeLUExact : MODE);
   const size_t lds = floats * sizeof(float);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   if (lds > 64 * 1024) {

@@ -1,0 +1,61 @@
+"""libALS.so loads and exports every symbol include/*.h declares (no compute, no GPU)."""
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_c_symbols():
+    text = open(os.path.join(ROOT, "include", "cumf_als_capi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cumf_[A-Za-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(alslib):
+    from cumf_als_amd import lib
+
+    declared = _declared_c_symbols()
+    assert set(declared) == set(lib.C_SYMBOLS), (declared, lib.C_SYMBOLS)
+    for s in declared + lib.CXX_SYMBOLS:
+        assert hasattr(alslib, s), s
+    assert alslib.cumf_als_arch() == b"gfx950"
+
+
+def test_mangled_names_match_the_reference_declarations(tmp_path):
+    """The C++ symbols are what a caller compiled against the reference's als.h / cg.h binds."""
+    src = tmp_path / "decl.cpp"
+    src.write_text('#include "als.h"\n#include "cg.h"\n'
+                   "void* a = (void*)&doALS; void* b = (void*)&updateXWithCGHost;\n")
+    obj = tmp_path / "decl.o"
+    subprocess.run(["g++", "-c", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(obj)], check=True)
+    syms = subprocess.run(["nm", "-u", str(obj)], capture_output=True, text=True, check=True).stdout
+    from cumf_als_amd import lib
+
+    for s in lib.CXX_SYMBOLS:
+        assert s in syms, s
+
+
+def test_kernels_are_gfx950_code_objects():
+    from cumf_als_amd import lib
+
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--list", "--type=o",
+                          f"--input={lib.LIB_PATH}"], capture_output=True, text=True)
+    if out.returncode == 0 and out.stdout.strip():
+        assert "gfx950" in out.stdout
+    else:  # fall back to the note section
+        raw = open(lib.LIB_PATH, "rb").read()
+        assert b"gfx950" in raw
+
+
+def test_product_never_touches_the_oracle():
+    """No file of the product path may reference oracle/ (a routed-through oracle voids parity)."""
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "cumf_als_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                text = open(os.path.join(base, fn), errors="ignore").read()
+                if re.search(r"\boracle\b", text) and "oracle" in text.replace("oracle's", "").replace("the oracle", ""):
+                    if re.search(r"(import|include|from|CDLL).*oracle", text):
+                        bad.append(os.path.join(base, fn))
+    assert not bad, bad
