@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -99,53 +100,78 @@ struct Stager {
   VT v[PASSES];
   float rv[PASSES];
   int cols[PASSES];
+  int cols_nx[PASSES];  // column indices one stage further ahead (steady-state loop)
 
-  // Column indices of the stage that starts at rating `begin` (nvalid >= 1 ratings).
-  // Issued one stage ahead of the gather that consumes them, so the gather never waits
-  // on a dependent load.
-  __device__ __forceinline__ void load_cols(const int* __restrict__ colidx, long long begin, int nvalid, int tid) {
+  // Everything below is branch-free on purpose: the steady-state stage loop must be ONE
+  // basic block so that (a) the compiler can count outstanding loads (a load under a branch
+  // degrades every s_waitcnt to vmcnt(0) and collapses the prefetch pipeline) and (b) the
+  // scheduler can thread these instructions between the MFMAs (sched_group_barrier).
+  // Out-of-range lanes/rows load from clamped in-bounds addresses and store to a dummy slot.
+
+  // Column indices of the stage that starts at rating `begin` (nvalid >= 1 ratings); issued
+  // at least one stage ahead of the gather that consumes them.
+  __device__ __forceinline__ void load_cols_into(int (&dst)[PASSES], const int* __restrict__ colidx, long long begin,
+                                                 int nvalid, int tid) {
     const int rsub = tid / LPR;
+    const int* base = colidx + begin;  // wave-uniform
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       const int r = rsub + p * RPP;
-      cols[p] = colidx[begin + (r < nvalid ? r : nvalid - 1)];
+      dst[p] = base[(unsigned)(r < nvalid ? r : nvalid - 1)];
     }
   }
+  __device__ __forceinline__ void load_cols(const int* __restrict__ colidx, long long begin, int nvalid, int tid) {
+    load_cols_into(cols, colidx, begin, nvalid, tid);
+  }
+  __device__ __forceinline__ void load_cols_next(const int* __restrict__ colidx, long long begin, int nvalid, int tid) {
+    load_cols_into(cols_nx, colidx, begin, nvalid, tid);
+  }
+  __device__ __forceinline__ void rotate_cols() {
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) cols[p] = cols_nx[p];
+  }
 
-  // Gather: lane (row r, piece pc) loads VW consecutive features of factor row cols[.].
-  // Every lane issues an in-bounds load (clamped address); nothing here consumes a loaded
-  // value, so the PASSES loads (and the rating loads of the slot-f lanes) stay in flight
-  // behind the MFMAs of the current stage.  Padding is zeroed in store().
+  // Gather pass p: lane (row r, piece pc) loads VW consecutive features of factor row
+  // cols[p] (32-bit byte offset from the wave-uniform table base: factor tables are < 4 GiB,
+  // checked at launch).  Nothing here consumes a loaded value, so the loads stay in flight
+  // behind the MFMAs.  The rating rides in feature slot f; every lane of the row loads it
+  // (same address, one broadcast).  Padding is zeroed in store_pass().
+  template <int P>
+  __device__ __forceinline__ void gather_pass(const float* __restrict__ val, const float* __restrict__ gat, int f,
+                                              long long begin, int nvalid, int tid) {
+    const int pc = tid % LPR, rsub = tid / LPR;
+    const int col0 = pc * VW;
+    const unsigned col0c = col0 < f ? col0 : 0;
+    const int r = rsub + P * RPP;
+    const unsigned off = (unsigned)cols[P] * (unsigned)f + col0c;  // in floats
+    v[P] = *reinterpret_cast<const VT*>(gat + off);
+    const float* vbase = val + begin;  // wave-uniform
+    rv[P] = vbase[(unsigned)(r < nvalid ? r : nvalid - 1)];
+  }
   __device__ __forceinline__ void gather(const float* __restrict__ val, const float* __restrict__ gat, int f,
                                          long long begin, int nvalid, int tid) {
-    const int pc = tid % LPR, rsub = tid / LPR;
-    const int col0 = pc * VW;
-    const int col0c = col0 < f ? col0 : 0;
-#pragma unroll
-    for (int p = 0; p < PASSES; ++p) v[p] = *reinterpret_cast<const VT*>(gat + (size_t)cols[p] * f + col0c);
-    if (col0 == f) {  // rating value rides in feature slot f
-#pragma unroll
-      for (int p = 0; p < PASSES; ++p) {
-        const int r = rsub + p * RPP;
-        rv[p] = val[begin + (r < nvalid ? r : nvalid - 1)];
-      }
-    }
+    static_for<PASSES>([&](auto pc) { gather_pass<decltype(pc)::value>(val, gat, f, begin, nvalid, tid); });
   }
 
-  // Rows [nvalid, nwrite) are written as zeros (nwrite = nvalid rounded up to 4).
-  __device__ __forceinline__ void store(float* __restrict__ stage, int f, int nvalid, int nwrite, int tid) const {
+  // Store pass p.  Rows [nvalid, nwrite) are written as zeros (nwrite = nvalid rounded up
+  // to 4).  Lanes beyond the row pitch / rows beyond nwrite store to `dummy` instead.
+  template <int P>
+  __device__ __forceinline__ void store_pass(float* __restrict__ stage, float* __restrict__ dummy, int f, int nvalid,
+                                             int nwrite, int tid) const {
     const int pc = tid % LPR, rsub = tid / LPR;
     const int col0 = pc * VW;
+    const int r = rsub + P * RPP;
+    VT x = v[P];
+    const bool live = (r < nvalid) && (col0 < f);
 #pragma unroll
-    for (int p = 0; p < PASSES; ++p) {
-      const int r = rsub + p * RPP;
-      VT x = v[p];
-      const bool live = (r < nvalid) && (col0 < f);
-#pragma unroll
-      for (int e = 0; e < VW; ++e) x[e] = live ? x[e] : 0.f;
-      if (col0 == f && r < nvalid) x[0] = rv[p];
-      if (pc < PPR && r < nwrite) *reinterpret_cast<VT*>(stage + r * Geo<NB>::LD + col0) = x;
-    }
+    for (int e = 0; e < VW; ++e) x[e] = live ? x[e] : 0.f;
+    x[0] = (col0 == f && r < nvalid) ? rv[P] : x[0];
+    float* dst = (pc < PPR && r < nwrite) ? stage + r * Geo<NB>::LD + col0 : dummy;
+    *reinterpret_cast<VT*>(dst) = x;
+  }
+  __device__ __forceinline__ void store(float* __restrict__ stage, float* __restrict__ dummy, int f, int nvalid,
+                                        int nwrite, int tid) const {
+    static_for<PASSES>([&](auto pc) { store_pass<decltype(pc)::value>(stage, dummy, f, nvalid, nwrite, tid); });
   }
 };
 
@@ -590,6 +616,8 @@ __device__ __forceinline__ void item_body(float* smem, const KernelArgs& a, int 
                                           int slot, int rowlen, int tid) {
   constexpr int LD = Geo<NB>::LD, TPW = Geo<NB>::TPW;
   constexpr int kStageFloats = kStage * LD;
+  constexpr int NG = kStage / 4;  // MFMA groups of 4 ratings per full stage
+  using St = Stager<NB, VT>;
   const int lane = tid & 63;
   f32x4 acc[TPW];
 #pragma unroll
@@ -597,29 +625,75 @@ __device__ __forceinline__ void item_body(float* smem, const KernelArgs& a, int 
 
   const int nstages = (len + kStage - 1) / kStage;
   auto nvalid_of = [&](int s) { return (len - s * kStage) < kStage ? (len - s * kStage) : kStage; };
-  Stager<NB, VT> st;
+  auto begin_of = [&](int s) { return begin + (long long)s * kStage; };
+  St st;
+  // landing slot for masked-off stage stores: inside the read-ahead pad behind the two stage
+  // buffers (read by nobody's MFMAs; in fused modes it is overwritten by G only after the
+  // last barrier of the loop)
+  float* dummy = smem + 2 * kStageFloats + 4 * LD + (tid & 15) * 4;
+  // Prologue: stage 0 into LDS buffer 0, stage 1 gathers in flight, column indices of stage 2.
   if (nstages > 0) {
     const int nv = nvalid_of(0);
     st.load_cols(a.colidx, begin, nv, tid);
     st.gather(a.val, a.gather, a.f, begin, nv, tid);
-    if (nstages > 1) st.load_cols(a.colidx, begin + kStage, nvalid_of(1), tid);
-    st.store(smem, a.f, nv, (nv + 3) & ~3, tid);
+    if (nstages > 1) st.load_cols(a.colidx, begin_of(1), nvalid_of(1), tid);
+    st.store(smem, dummy, a.f, nv, (nv + 3) & ~3, tid);
+    if (nstages > 1) {
+      st.gather(a.val, a.gather, a.f, begin_of(1), nvalid_of(1), tid);
+      if (nstages > 2) st.load_cols(a.colidx, begin_of(2), nvalid_of(2), tid);
+    }
   }
   __syncthreads();
-  for (int s = 0; s < nstages; ++s) {
-    const int nv = nvalid_of(s);
-    const bool more = (s + 1 < nstages);
-    int nv_next = 0;
-    if (more) {
-      nv_next = nvalid_of(s + 1);
-      if (!(a.dbg & 1))
-        st.gather(a.val, a.gather, a.f, begin + (long long)(s + 1) * kStage, nv_next, tid);  // cols came a stage ago
-      if (s + 2 < nstages && !(a.dbg & 2))
-        st.load_cols(a.colidx, begin + (long long)(s + 2) * kStage, nvalid_of(s + 2), tid);
-    }
-    if (!(a.dbg & 4)) mma_stage<NB, W>(smem + (s & 1) * kStageFloats, acc, (nv + 3) >> 2, lane);
-    if (more && !(a.dbg & 8)) st.store(smem + ((s + 1) & 1) * kStageFloats, a.f, nv_next, (nv_next + 3) & ~3, tid);
-    if (!(a.dbg & 16)) __syncthreads();
+
+  // Steady state.  Every stage but the last is full (32 ratings = NG groups).  While the
+  // MFMAs of group g drain through the matrix pipe the wave issues, in their shadow, one
+  // slice of the staging work: the LDS store of pass p of stage s+1 (gathered during stage
+  // s-1, so it has landed) immediately followed by the gather of pass p of stage s+2 into
+  // the same registers; after the last slice the column indices of stage s+3.
+  const float* rowbase = smem + (lane >> 4) * LD + (lane & 15);
+  auto load_blk = [&](float (&blk)[NB], const float* p) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) blk[b] = p[16 * b];
+  };
+  for (int s = 0; s + 1 < nstages; ++s) {
+    const float* cur = rowbase + (s & 1) * kStageFloats;
+    float* nxt = smem + ((s + 1) & 1) * kStageFloats;
+    const int nv1 = nvalid_of(s + 1), nw1 = (nv1 + 3) & ~3;
+    // stages s+2 / s+3 may not exist near the end of the item: the loads are then issued
+    // anyway on the last existing stage (in-bounds, never stored) to keep the loop branch-free
+    const int s2 = (s + 2 < nstages) ? s + 2 : nstages - 1;
+    const int s3 = (s + 3 < nstages) ? s + 3 : nstages - 1;
+    const int nv2 = nvalid_of(s2), nv3 = nvalid_of(s3);
+    const long long b2 = begin_of(s2), b3 = begin_of(s3);
+    float blk_a[NB], blk_b[NB];
+    load_blk(blk_a, cur);
+    static_for<NG>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      float (&bc)[NB] = (g & 1) ? blk_b : blk_a;
+      float (&bn)[NB] = (g & 1) ? blk_a : blk_b;
+      if constexpr (g + 1 < NG) load_blk(bn, cur + (g + 1) * 4 * LD);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_group<NB, W>(bc, acc);
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<St::PASSES>([&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        if constexpr (p * NG / St::PASSES == g) {
+          st.template store_pass<p>(nxt, dummy, a.f, nv1, nw1, tid);
+          st.template gather_pass<p>(a.val, a.gather, a.f, b2, nv2, tid);
+        }
+      });
+      if constexpr (g == 0) st.load_cols_next(a.colidx, b3, nv3, tid);  // consumed a whole stage later
+      // (threading the slice between the seven MFMAs with sched_group_barrier measured ~3 %
+      //  slower than issuing it after them: tools/mfma_ladder.hip, F=63 vs F=127)
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    st.rotate_cols();
+    __syncthreads();
+  }
+  if (nstages > 0) {
+    const int sl = nstages - 1;
+    mma_stage<NB, W>(smem + (sl & 1) * kStageFloats, acc, (nvalid_of(sl) + 3) >> 2, lane);
+    __syncthreads();  // every wave is done with the stage buffers (G aliases them)
   }
   if (slot >= 0)
     tiles_to_partial<NB, W>(acc, a.part + (size_t)slot * Geo<NB>::NT * 256, lane);
@@ -851,7 +925,8 @@ static hipError_t launch_nb(const KernelArgs& a, long n_items, long n_mrows, hip
     const size_t solve = solve_lds_floats(a.f, MODE);
     floats = floats > solve ? floats : solve;
   }
-  const size_t lds = floats * sizeof(float);
+  static const size_t lds_pad = getenv("CUMF_ALS_LDS_PAD") ? (size_t)atol(getenv("CUMF_ALS_LDS_PAD")) : 0;  // occupancy experiments
+  const size_t lds = floats * sizeof(float) + lds_pad;
   hipError_t e;
   if (lds > 64 * 1024) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(als_item_kernel<NB, VT, MODE>),
