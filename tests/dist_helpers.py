@@ -1,0 +1,79 @@
+"""Stand-in compute ops for the multi-process CPU tests of cumf_als_amd.dist.
+
+TEST INFRASTRUCTURE: the product's ops are `cumf_als_amd.dist.HipOps` (HIP kernels).  There
+is no GPU in the CPU test tier, so the partition + collective logic of DistALS is exercised
+with the CPU oracle doing the per-rank arithmetic.  Never imported by the package.
+"""
+import numpy as np
+import torch
+
+from oracle import pyoracle
+
+
+class _Plan:
+    def __init__(self, rowptr, f, row_begin, row_end):
+        self.rowptr = np.ascontiguousarray(rowptr).astype(np.int32)
+        self.f = f
+        self.row_begin = row_begin
+        self.row_end = len(rowptr) - 1 if row_end is None else row_end
+
+
+class OracleOps:
+    device = torch.device("cpu")
+
+    def to_device(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a))
+
+    def plan(self, rowptr, f, chunk=0, row_begin=0, row_end=None):
+        return _Plan(rowptr, f, row_begin, row_end)
+
+    def update_fused(self, plan, colidx, val, gather, update, lam, solver, cg_iters):
+        out = update.numpy()
+        assert plan.row_begin == 0 and plan.row_end == len(plan.rowptr) - 1
+        x = np.ascontiguousarray(out, np.float32)
+        pyoracle.half_iteration(plan.rowptr, colidx.numpy(), val.numpy(), gather.numpy(), x, plan.f, lam,
+                                solver=solver, cg_iters=cg_iters)
+        update.copy_(torch.from_numpy(x))
+
+    def get_hermitian(self, plan, colidx, val, gather, lam, tt, rhs):
+        A, b = pyoracle.gram_rhs(plan.rowptr, colidx.numpy(), val.numpy(), gather.numpy(), plan.f, lam,
+                                 plan.row_begin, plan.row_end)
+        tt.copy_(torch.from_numpy(A))
+        rhs.copy_(torch.from_numpy(b))
+
+    def solve(self, tt, rhs, x, solver, cg_iters):
+        f = rhs.shape[-1]
+        if solver in ("cg", 0):
+            out = pyoracle.cg(tt.numpy(), x.numpy(), rhs.numpy(), f, cg_iters)
+        else:
+            out = pyoracle.lu(tt.numpy(), rhs.numpy(), f)
+        x.copy_(torch.from_numpy(np.ascontiguousarray(out, np.float32)))
+
+
+def worker(rank, world, port, scheme, solver, d, m, n, f, lam, iters, theta_batch, theta0, q, ops_kind="oracle"):
+    """Entry point of one rank (spawned): runs DistALS and returns full factors through `q`."""
+    import os
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cumf_als_amd import dist as cdist
+
+        if ops_kind == "hip":
+            torch.cuda.set_device(0)
+            ops = cdist.HipOps("cuda:0")
+        else:
+            ops = OracleOps()
+        mat = cdist.HostMatrix(m, n, d["csr_indptr"], d["csr_indices"], d["csr_data"], d["csc_indptr"],
+                               d["csc_indices"], d["csc_data"])
+        eng = cdist.DistALS(mat, f, lam, ops, solver=solver, cg_iters=6, scheme=scheme, theta_batch=theta_batch)
+        eng.init_factors(theta0)
+        eng.iterate(iters)
+        x = eng.full_XT().cpu().numpy().copy()
+        th = eng.thetaT.cpu().numpy().copy()
+        q.put((rank, th, x))
+    finally:
+        dist.destroy_process_group()

@@ -1,0 +1,42 @@
+"""N > 1 path with the real HIP kernels: two processes share cuda:0 (the GPU box has one
+GPU), collectives go through gloo with host staging.  Same expectations as the CPU tier."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("scheme,solver", [("gather", "lu"), ("reduce", "lu"), ("reduce", "cg")])
+def test_world2_hip_matches_single_process(oracle, alslib, scheme, solver):
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    import torch.multiprocessing as mp
+
+    from cumf_als_amd import datagen
+    from tests import dist_helpers
+    from tests.test_dist_cpu import _free_port
+
+    m, n, f, lam, iters = 120, 90, 20, 0.05, 2
+    r = datagen.synth_ratings(m, n, 6000, 600, seed=12, row_alpha=1.1)
+    d = r.numpy()
+    theta0 = (0.2 * np.random.RandomState(0).random_sample((n, f))).astype(np.float32)
+    th_ref, x_ref = theta0.copy(), np.zeros((m, f), np.float32)
+    oracle.do_als(d, th_ref, x_ref, m, n, f, lam, iters, solver=solver)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=dist_helpers.worker,
+                         args=(rk, 2, port, scheme, solver, d, m, n, f, lam, iters, 2, theta0, q, "hip"))
+             for rk in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted((q.get(timeout=600) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    tol = 2e-4 if solver == "lu" else 3e-3
+    for rank, th, x in outs:
+        assert np.abs(th - th_ref).max() <= tol * np.abs(th_ref).max()
+        assert np.abs(x - x_ref).max() <= tol * np.abs(x_ref).max()
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
