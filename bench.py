@@ -43,37 +43,59 @@ def alg_bytes(nnz: int, rows: int, f: int, cg: bool) -> float:
     return b
 
 
-def cpu_baseline(d, f, lam, solver, frac=0.125):
-    """Oracle half-iterations (all host cores, OpenMP) on the first rows holding ~frac of nnz."""
+def cpu_baseline(d, f, lam, solver, target_s=16.0):
+    """Oracle half-iterations (all host cores, OpenMP over rows) on a row sample of the same
+    matrix sized for ~target_s seconds of wall time: a 1/64 probe sets the rate, the sized
+    sample (capped at the whole matrix) is what is reported."""
     from oracle import pyoracle
 
     pyoracle.build()
     rng = np.random.RandomState(0)
-    out = {}
-    tot_nnz, tot_t = 0, 0.0
-    for side, (ptr, idx, val, gather_rows) in {
+    sides = {
         "x": (d["csr_indptr"], d["csr_indices"], d["csr_data"], len(d["csc_indptr"]) - 1),
         "theta": (d["csc_indptr"], d["csc_indices"], d["csc_data"], len(d["csr_indptr"]) - 1),
-    }.items():
-        target = int(ptr[-1] * frac)
-        rows = int(np.searchsorted(ptr, target, side="left"))
-        rows = max(rows, 1)
-        nn = int(ptr[rows])
-        gather = (0.2 * rng.random_sample((gather_rows, f))).astype(np.float32)
-        update = np.zeros((rows, f), np.float32)
-        t = pyoracle.time_half_iteration(ptr[:rows + 1], idx[:nn], val[:nn], gather, update, f, lam, solver=solver)
-        out[side] = (rows, nn, t)
-        tot_nnz += nn
-        tot_t += t
+    }
+    gathers = {k: (0.2 * rng.random_sample((v[3], f))).astype(np.float32) for k, v in sides.items()}
+
+    def run(frac):
+        out, tot_nnz, tot_t = {}, 0, 0.0
+        for side, (ptr, idx, val, _) in sides.items():
+            rows = max(1, int(np.searchsorted(ptr, int(ptr[-1] * frac), side="left")))
+            rows = min(rows, len(ptr) - 1)
+            nn = int(ptr[rows])
+            update = np.zeros((rows, f), np.float32)
+            t = pyoracle.time_half_iteration(ptr[:rows + 1], idx[:nn], val[:nn], gathers[side], update, f, lam,
+                                             solver=solver)
+            out[side] = (rows, nn, t)
+            tot_nnz += nn
+            tot_t += t
+        return out, tot_nnz, tot_t
+
+    _, pn, pt = run(1.0 / 64)
+    frac = min(1.0, max(1.0 / 64, (target_s / max(pt, 1e-6)) / 64))
+    out, tot_nnz, tot_t = run(frac)
     return {
         "value": tot_nnz / tot_t,
         "unit": "ratings/s",
         "cores": pyoracle.num_threads(),
         "kind": "port",
-        "sample": (f"one X and one Theta half-iteration of the CPU oracle (fp32, OpenMP over rows) on the first "
-                   f"{out['x'][0]} X rows ({out['x'][1]} ratings, {out['x'][2]:.2f} s) and first {out['theta'][0]} "
-                   f"Theta rows ({out['theta'][1]} ratings, {out['theta'][2]:.2f} s) of the same synthetic matrix"),
+        "sample": (f"one X and one Theta half-iteration of the CPU oracle (fp32, {solver.upper()} solver, OpenMP over "
+                   f"rows, {pyoracle.num_threads()} threads) on the first {out['x'][0]} X rows ({out['x'][1]} ratings, "
+                   f"{out['x'][2]:.2f} s) and the first {out['theta'][0]} Theta rows ({out['theta'][1]} ratings, "
+                   f"{out['theta'][2]:.2f} s) of the same synthetic matrix ({100 * frac:.0f} % of its ratings per side)"),
     }
+
+
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (tools/collect_profiles.sh -> profiles/): (2 * FETCH_SIZE + WRITE_SIZE) KiB, FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for gfx950.  None when no profile is committed."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as fh:
+            return json.load(fh)
+    except (OSError, ValueError):
+        return None
 
 
 def main() -> int:
@@ -208,7 +230,8 @@ def main() -> int:
         out["roofline"] = {
             "bound": "hbm", "kernel": "cumf::als_item_kernel<7, float4, LU>" if (f == 100 and not cg) else "cumf::als_item_kernel",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": (measured_traffic() or {}).get("bytes_per_launch"),
+            "traffic_source": (measured_traffic() or {}).get("source"),
             "alg_bytes_per_launch": avg_bytes, "avg_launch_ms": avg_ms,
             "x_side_ms": sum(x_ms) / len(x_ms), "theta_side_ms": sum(t_ms) / len(t_ms),
             "reduce_kernel_ms_x_side": sum(red_ms[0::2]) / len(red_ms[0::2]),
