@@ -1020,8 +1020,18 @@ static hipError_t launch_solve_mode(const float* A, const float* b, float* x, lo
     case 7: return launch_solve_nb<7, MODE>(A, b, x, batch, f, cg_iters, stream);
     case 8: return launch_solve_nb<8, MODE>(A, b, x, batch, f, cg_iters, stream);
     case 9: return launch_solve_nb<9, MODE>(A, b, x, batch, f, cg_iters, stream);
-    default: return hipErrorInvalidValue;
+    default: break;
   }
+  if constexpr (MODE == kModeLU) {  // register-resident elimination also for 128 < f <= 200 (G alone fills the LDS)
+    switch (nb_for_f(f)) {
+      case 10: return launch_solve_nb<10, MODE>(A, b, x, batch, f, cg_iters, stream);
+      case 11: return launch_solve_nb<11, MODE>(A, b, x, batch, f, cg_iters, stream);
+      case 12: return launch_solve_nb<12, MODE>(A, b, x, batch, f, cg_iters, stream);
+      case 13: return launch_solve_nb<13, MODE>(A, b, x, batch, f, cg_iters, stream);
+      default: break;
+    }
+  }
+  return hipErrorInvalidValue;
 }
 
 hipError_t launch_solve_batched(const float* A, const float* b, float* x, long batch, int f, int mode, int cg_iters,
@@ -1034,7 +1044,8 @@ hipError_t launch_solve_batched(const float* A, const float* b, float* x, long b
       hipLaunchKernelGGL(cg_global_kernel, dim3((unsigned)batch), dim3(threads), lds, stream, A, x, b, f, cg_iters);
       return hipGetLastError();
     }
-    return launch_solve_nb<0, kModeLU>(A, b, x, batch, f, 0, stream);  // LDS-resident exact-order LU
+    if (mode == kModeLUExact) return launch_solve_nb<0, kModeLU>(A, b, x, batch, f, 0, stream);
+    return launch_solve_mode<kModeLU>(A, b, x, batch, f, cg_iters, stream);
   }
   if (mode == kModeCG) return launch_solve_mode<kModeCG>(A, b, x, batch, f, cg_iters, stream);
   if (mode == kModeLUExact) return launch_solve_nb<0, kModeLU>(A, b, x, batch, f, 0, stream);

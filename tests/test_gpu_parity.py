@@ -75,7 +75,7 @@ def test_gram_chunked_rows(oracle, alslib, f, chunk):
 @pytest.mark.parametrize("f", [10, 40, 100, 128, 200])
 def test_lu_solve(oracle, alslib, f, monkeypatch):
     """Batched unpivoted LU.  CUMF_ALS_LU_EXACT=1 (LDS elimination in the oracle's operation
-    order; also what f > 128 uses): bit-exact.  Default (register-resident symmetric
+    order): bit-exact.  Default (register-resident symmetric
     elimination, l = u_ki * (1/u_kk)): same solution to 2e-5 relative."""
     _need_gpu()
     from cumf_als_amd import als
