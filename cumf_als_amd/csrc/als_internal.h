@@ -27,7 +27,7 @@ __host__ __device__ constexpr size_t solve_g_floats(int f, int mode) {
 constexpr int kCgExtraFloats = 12 * kVecLd;  // 4 per-wave operand copies + 2 x 4 partial mat-vecs
 // whole LDS footprint of a solve: G + CG exchange buffers | G + pivot reciprocals (fast LU)
 __host__ __device__ constexpr size_t solve_lds_floats(int f, int mode) {
-  return solve_g_floats(f, mode) + (mode == kModeCG ? (size_t)kCgExtraFloats : (mode == kModeLU ? (size_t)2 * kVecLd : 0));
+  return solve_g_floats(f, mode) + (mode == kModeCG ? (size_t)kCgExtraFloats : (mode == kModeLU ? (size_t)((f + 3) & ~3) : 0));  // LU: + f pivot reciprocals (f = 100: 40 800 B -> 4 workgroups per CU)
 }
 
 struct KernelArgs {

@@ -530,11 +530,13 @@ __device__ __forceinline__ void lu_solve_reg(float* __restrict__ G, int ldg, int
       const int k = 16 * kb + kk;
       if (k >= f) break;
       if (ti == kk) {  // this thread row owns pivot row k: publish it (= final row k of U)
+        float* urow_w = G + k * ldg + tj;
         static_for<NB>([&](auto bjc) {
           constexpr int bj = decltype(bjc)::value;
-          if constexpr (bj >= kb) {
-            const int j = 16 * bj + tj;
-            if (j <= f) G[k * ldg + j] = a[kb][bj];
+          // blocks below NB-1 lie entirely left of column f (NB = f/16 + 1): no predicate
+          if constexpr (bj >= kb && bj < NB - 1) urow_w[16 * bj] = a[kb][bj];
+          if constexpr (bj >= kb && bj == NB - 1) {
+            if (16 * bj + tj <= f) urow_w[16 * bj] = a[kb][bj];
           }
         });
       }
