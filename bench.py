@@ -134,12 +134,22 @@ def main() -> int:
 
     shp = datagen.SHAPES[a.shape]
     s = a.scale
-    m, n = max(2, int(shp["m"] * s)), max(2, int(shp["n"] * s))
-    nnz, nnz_test = max(int(shp["nnz"] * s * s), m + n), max(int(shp["nnz_test"] * s * s), 512)
     lam, f = shp["lam"], a.f
-
+    slab_mode = a.shape == "hugewiki"
     t0 = time.time()
-    r = datagen.synth_ratings(m, n, nnz, nnz_test, seed=a.seed, device=dev)
+    if slab_mode:
+        # hugewiki scale (BASELINE.json configs[3]): WEAK scaling, every rank generates and keeps
+        # one row slab of 1/8 of the hugewiki matrix (6.26 M x 39 780, 388 M ratings); the
+        # "reduce" scheme never materialises the whole matrix anywhere.
+        m_slab, n = max(2, int(shp["m"] * s) // 8), max(2, int(shp["n"] * s))
+        nnz_slab = max(int(shp["nnz"] * s * s) // 8, m_slab + n)
+        r = datagen.synth_ratings(m_slab, n, nnz_slab, 4096, seed=a.seed + 1000 * (rank + 1), device=dev,
+                                  col_seed=a.seed)
+        m, nnz = m_slab * world, nnz_slab * world
+    else:
+        m, n = max(2, int(shp["m"] * s)), max(2, int(shp["n"] * s))
+        nnz, nnz_test = max(int(shp["nnz"] * s * s), m + n), max(int(shp["nnz_test"] * s * s), 512)
+        r = datagen.synth_ratings(m, n, nnz, nnz_test, seed=a.seed, device=dev)
     torch.cuda.synchronize()
     t_gen = time.time() - t0
     g = torch.Generator(device="cpu")
@@ -147,8 +157,12 @@ def main() -> int:
     theta0 = (0.2 * torch.rand((n, f), generator=g, dtype=torch.float32)).numpy()
 
     item_ms = []
-    if world == 1:
-        eng = als.ALSEngine(r, f, lam, solver=a.solver, cg_iters=a.cg_iters)
+    if slab_mode:
+        from cumf_als_amd import dist as cdist
+
+        xb = np.arange(world + 1, dtype=np.int64) * r.m
+        eng = cdist.DistALS.from_local_slab(m, n, xb, r.csr_indptr, r.csr_indices, r.csr_data, f, lam,
+                                            cdist.HipOps(dev), solver=a.solver, cg_iters=a.cg_iters)
         eng.init_factors(theta0)
 
         def step(timed):
@@ -161,6 +175,13 @@ def main() -> int:
 
         def barrier():
             torch.cuda.synchronize()
+            if world > 1:
+                import torch.distributed as dist
+
+                dist.barrier()
+                torch.cuda.synchronize()
+    elif world == 1:
+        eng = als.ALSEngine(r, f, lam, solver=a.solver, cg_iters=a.cg_iters)
     else:
         import torch.distributed as dist
 
@@ -203,16 +224,17 @@ def main() -> int:
             "metric": "ratings/sec per ALS half-iteration (Netflix f=100); RMSE vs reference",
             "value": value, "unit": "ratings/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak" if slab_mode else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{a.shape}-shape synthetic ratings {m}x{n}, nnz={nnz}, f={f}, "
                                    f"lambda={lam}, solver={a.solver}"
                                    + (f"(cg_iters={a.cg_iters})" if a.solver == "cg" else "")
-                                   + (", X_BATCH=1 THETA_BATCH=1, fused Gram+solve" if world == 1
+                                   + (f", row slab per GPU (1/8 hugewiki), reduce scheme over {world} GPU(s)" if slab_mode
+                                      else ", X_BATCH=1 THETA_BATCH=1, fused Gram+solve" if world == 1
                                       else f", {a.scheme} scheme over {world} GPUs"),
                        "step": "update-X + update-Theta (two half-iterations)", "gen_seconds": round(t_gen, 2)},
         }
 
-    if world == 1:
+    if world == 1 and not slab_mode:
         # roofline leg: the same steps again with HIP events around each kernel launch
         als.set_kernel_timing(True)
         for _ in range(max(2, min(a.steps, 5))):

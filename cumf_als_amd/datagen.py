@@ -110,7 +110,7 @@ def _sample_pairs(m, n, count, cdf_r, cdf_c, gen, device):
 def synth_ratings(m: int, n: int, nnz: int, nnz_test: int, seed: int = 0, *,
                   row_alpha: float = 0.9, col_alpha: float = 0.9, rank: int = 8,
                   noise: float = 0.4, ensure_nonempty: bool = True,
-                  device: str | torch.device = "cpu") -> Ratings:
+                  device: str | torch.device = "cpu", col_seed: int | None = None) -> Ratings:
     """Generate `nnz` train + `nnz_test` test ratings of an m x n matrix.
 
     Row/column degrees follow shuffled power laws (alpha = 0 gives the uniform
@@ -125,7 +125,12 @@ def synth_ratings(m: int, n: int, nnz: int, nnz_test: int, seed: int = 0, *,
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
     cdf_r = _powerlaw_cdf(m, row_alpha, gen, device)
-    cdf_c = _powerlaw_cdf(n, col_alpha, gen, device)
+    if col_seed is None:
+        cdf_c = _powerlaw_cdf(n, col_alpha, gen, device)
+    else:  # row slabs of one matrix generated by different ranks share the column popularity
+        cgen = torch.Generator(device=device)
+        cgen.manual_seed(col_seed)
+        cdf_c = _powerlaw_cdf(n, col_alpha, cgen, device)
 
     forced = torch.empty(0, dtype=torch.int64, device=device)
     if ensure_nonempty:
@@ -165,7 +170,10 @@ def synth_ratings(m: int, n: int, nnz: int, nnz_test: int, seed: int = 0, *,
 
     # planted low-rank model -> ratings in {1..5}
     gx = torch.randn(m, rank, generator=gen, device=device) / rank ** 0.25
-    gt = torch.randn(n, rank, generator=gen, device=device) / rank ** 0.25
+    if col_seed is None:
+        gt = torch.randn(n, rank, generator=gen, device=device) / rank ** 0.25
+    else:
+        gt = torch.randn(n, rank, generator=cgen, device=device) / rank ** 0.25
 
     def rate(k):
         rr = torch.div(k, n, rounding_mode="floor")

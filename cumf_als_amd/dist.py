@@ -71,6 +71,19 @@ def local_csc_of_slab(rowptr_l, colidx_l, val_l, n_cols: int):
     return colptr.astype(rowptr_l.dtype), row_of[order].astype(np.int32), val_l[order]
 
 
+def local_csc_of_slab_torch(rowptr_l: torch.Tensor, colidx_l: torch.Tensor, val_l: torch.Tensor, n_cols: int):
+    """Same as `local_csc_of_slab`, on the device with torch ops (hugewiki-size slabs: 388 M
+    ratings per GPU).  Returns (colptr int64 on host as numpy, rowidx int32, val) -- the last two
+    on the device."""
+    rows = rowptr_l.numel() - 1
+    counts = (rowptr_l[1:] - rowptr_l[:-1]).to(torch.int64)
+    row_of = torch.repeat_interleave(torch.arange(rows, device=colidx_l.device, dtype=torch.int64), counts)
+    order = torch.argsort(colidx_l.to(torch.int64) * rows + row_of)
+    colptr = torch.zeros(n_cols + 1, dtype=torch.int64, device=colidx_l.device)
+    colptr[1:] = torch.cumsum(torch.bincount(colidx_l, minlength=n_cols), 0)
+    return colptr.cpu().numpy(), row_of[order].to(torch.int32), val_l[order]
+
+
 # ----------------------------------------------------------------------------------------
 # compute ops (product = HIP kernels through the C ABI)
 # ----------------------------------------------------------------------------------------
@@ -131,6 +144,8 @@ def all_gather_rows(out: torch.Tensor, mine: torch.Tensor, bounds, group=None) -
 
 def reduce_scatter_rows(full: torch.Tensor, group=None) -> torch.Tensor:
     """Sum `full` ([world * k, ...]) over ranks and return this rank's k rows."""
+    if not dist.is_initialized():
+        return full
     world = dist.get_world_size(group)
     k = full.shape[0] // world
     if _needs_host_staging(full) or not full.is_cuda:
@@ -145,6 +160,9 @@ def reduce_scatter_rows(full: torch.Tensor, group=None) -> torch.Tensor:
 
 
 def all_gather_equal(out: torch.Tensor, mine: torch.Tensor, group=None) -> None:
+    if not dist.is_initialized():
+        out.copy_(mine)
+        return
     if _needs_host_staging(out):
         recv = torch.empty(out.shape, dtype=out.dtype)
         dist.all_gather_into_tensor(recv, mine.cpu(), group=group)
@@ -215,6 +233,37 @@ class DistALS:
                 self.t_batches.append((off, size, ops.plan(cp, f, chunk, off, off + size)))
         else:
             raise ValueError(scheme)
+
+    @classmethod
+    def from_local_slab(cls, m_total: int, n: int, xb, rowptr_l: torch.Tensor, colidx_l: torch.Tensor,
+                        val_l: torch.Tensor, f: int, lam: float, ops, solver="cg", cg_iters: int = 6,
+                        theta_batch: int = 1, group=None, chunk: int = 0) -> "DistALS":
+        """`reduce` scheme from this rank's row slab only (hugewiki scale: no rank ever holds the
+        whole matrix -- the reference pre-splits it into per-GPU files, hugewiki.cu:2332-2340).
+        `xb`: the world+1 global slab boundaries; the three tensors are the slab's CSR with the
+        row pointer rebased to 0, already on the device."""
+        self = cls.__new__(cls)
+        self.f, self.lam, self.ops = f, float(lam), ops
+        self.solver, self.cg_iters, self.scheme = solver, cg_iters, "reduce"
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.m, self.n = m_total, n
+        self.theta_batch = theta_batch
+        self.xb = np.asarray(xb, dtype=np.int64)
+        dev = colidx_l.device
+        self.thetaT = torch.zeros((n, f), dtype=torch.float32, device=dev)
+        self.x_rows = rowptr_l.numel() - 1
+        self.x_plan = ops.plan(rowptr_l.cpu().numpy(), f, chunk)
+        self.x_colidx, self.x_val = colidx_l, val_l
+        self.XT = torch.zeros((self.x_rows, f), dtype=torch.float32, device=dev)
+        cp, self.lc_rowidx, self.lc_val = local_csc_of_slab_torch(rowptr_l, colidx_l, val_l, n)
+        self.t_batches = []
+        for b in range(theta_batch):
+            size = n // theta_batch if b != theta_batch - 1 else n - b * (n // theta_batch)
+            off = b * (n // theta_batch)
+            self.t_batches.append((off, size, ops.plan(cp, f, chunk, off, off + size)))
+        return self
 
     # -- factors ---------------------------------------------------------------------------
     def init_factors(self, thetaT: np.ndarray, XT: np.ndarray | None = None) -> None:

@@ -40,3 +40,33 @@ def test_world2_hip_matches_single_process(oracle, alslib, scheme, solver):
         assert np.abs(th - th_ref).max() <= tol * np.abs(th_ref).max()
         assert np.abs(x - x_ref).max() <= tol * np.abs(x_ref).max()
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("solver", ["lu", "cg"])
+def test_local_slab_reduce_single_rank(oracle, alslib, solver):
+    """`DistALS.from_local_slab` (hugewiki path: slab-local CSC built on the device, partial Gram
+    -> reduce-scatter -> solve -> all-gather) with one rank == plain ALS."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    from cumf_als_amd import datagen
+    from cumf_als_amd import dist as cdist
+
+    m, n, f, lam, iters = 150, 60, 20, 0.05, 2
+    r = datagen.synth_ratings(m, n, 4000, 300, seed=5, col_seed=7).to("cuda")
+    d = r.numpy()
+    theta0 = (0.2 * np.random.RandomState(0).random_sample((n, f))).astype(np.float32)
+    th_ref, x_ref = theta0.copy(), np.zeros((m, f), np.float32)
+    oracle.do_als(d, th_ref, x_ref, m, n, f, lam, iters, solver=solver)
+    eng = cdist.DistALS.from_local_slab(m, n, [0, m], r.csr_indptr, r.csr_indices, r.csr_data, f, lam,
+                                        cdist.HipOps("cuda"), solver=solver, theta_batch=3)
+    eng.init_factors(theta0)
+    eng.iterate(iters)
+    torch.cuda.synchronize()
+    tol = 2e-4 if solver == "lu" else 3e-3
+    assert np.abs(eng.thetaT.cpu().numpy() - th_ref).max() <= tol * np.abs(th_ref).max()
+    assert np.abs(eng.XT.cpu().numpy() - x_ref).max() <= tol * np.abs(x_ref).max()
+    # the device-side CSC build agrees with scipy's ordering
+    cp, ri, cv = cdist.local_csc_of_slab_torch(r.csr_indptr, r.csr_indices, r.csr_data, n)
+    assert np.array_equal(cp, d["csc_indptr"]) and np.array_equal(ri.cpu().numpy(), d["csc_indices"])
+    assert np.array_equal(cv.cpu().numpy(), d["csc_data"])
