@@ -182,6 +182,18 @@ def main() -> int:
                 torch.cuda.synchronize()
     elif world == 1:
         eng = als.ALSEngine(r, f, lam, solver=a.solver, cg_iters=a.cg_iters)
+        eng.init_factors(theta0)
+
+        def step(timed):
+            eng.update_x()
+            if timed:
+                item_ms.append(als.last_kernel_ms())
+            eng.update_theta()
+            if timed:
+                item_ms.append(als.last_kernel_ms())
+
+        def barrier():
+            torch.cuda.synchronize()
     else:
         import torch.distributed as dist
 

@@ -92,86 +92,114 @@ __device__ __forceinline__ float wave_sum(float v) {
 template <int NB, typename VT>
 struct Stager {
   static constexpr int VW = sizeof(VT) / 4;
-  static constexpr int PPR = Geo<NB>::LD / VW;        // vector pieces per stage row
+  static constexpr int LD = Geo<NB>::LD;
+  static constexpr int PPR = LD / VW;                 // vector pieces per stage row
   static constexpr int LPR = PPR <= 32 ? 32 : (PPR <= 64 ? 64 : 128);  // lanes covering one row (power of two)
   static constexpr int RPP = kThreads / LPR;          // rows per pass
   static constexpr int PASSES = kStage / RPP;
   static_assert(PPR <= 128, "stage row too wide");
-  VT v[PASSES];
-  float rv[PASSES];
-  int cols[PASSES];
-  int cols_nx[PASSES];  // column indices one stage further ahead (steady-state loop)
+  VT v[PASSES];        // gathered factor-row pieces of one stage
+  float rvv;           // rating of row (tid & 31) of that stage
+  int cols[PASSES];    // column indices feeding the next gather
+  int cols_nx[PASSES]; // column indices one stage further ahead
+  // loop-invariant per-thread state
+  unsigned goff;       // byte offset of this lane's piece inside a factor row (clamped)
+  int lds_row0;        // float offset of (row rsub, this piece) inside a stage buffer
+  bool feat;           // this lane's piece holds features (col0 < f)
+  int rsub, col0;
 
-  // Everything below is branch-free on purpose: the steady-state stage loop must be ONE
-  // basic block so that (a) the compiler can count outstanding loads (a load under a branch
-  // degrades every s_waitcnt to vmcnt(0) and collapses the prefetch pipeline) and (b) the
-  // scheduler can thread these instructions between the MFMAs (sched_group_barrier).
-  // Out-of-range lanes/rows load from clamped in-bounds addresses and store to a dummy slot.
+  // The steady-state stage loop must stay ONE basic block with as few VALU instructions as
+  // possible: measured with tools/mfma_ladder.hip, every VALU instruction issued next to the
+  // MFMAs costs matrix-pipe time, and a load under a branch degrades every s_waitcnt to
+  // vmcnt(0).  So: full stages take a select-free path (feature lanes store what they loaded,
+  // the zero padding of the stage rows is written once per item, the rating goes through its
+  // own 4-byte store), addresses are 32-bit offsets from wave-uniform bases (factor tables
+  // are < 4 GiB), and only the last -- possibly ragged -- stage of an item uses masked stores.
+  __device__ __forceinline__ void init(int f, int tid) {
+    const int pc = tid % LPR;
+    rsub = tid / LPR;
+    col0 = pc * VW;
+    feat = col0 < f;
+    goff = feat ? (unsigned)col0 * 4u : 0u;
+    lds_row0 = rsub * LD + col0;
+  }
 
-  // Column indices of the stage that starts at rating `begin` (nvalid >= 1 ratings); issued
-  // at least one stage ahead of the gather that consumes them.
+  // Zero the padding of both stage buffers: columns [f, LD) of every row (the rating slot f
+  // is overwritten per stage).  Needed once per item (the solvers' G aliases the buffers).
+  __device__ __forceinline__ void zero_padding(float* __restrict__ smem, int f, int tid) const {
+    const int pad = LD - f;  // floats per row, a multiple of VW
+    for (int e = tid; e < 2 * kStage * (pad / VW); e += kThreads) {
+      const int row = e / (pad / VW), k = e - row * (pad / VW);
+      VT z = {};
+      *reinterpret_cast<VT*>(smem + row * LD + f + k * VW) = z;
+    }
+  }
+
+  template <bool FULL>
   __device__ __forceinline__ void load_cols_into(int (&dst)[PASSES], const int* __restrict__ colidx, long long begin,
-                                                 int nvalid, int tid) {
-    const int rsub = tid / LPR;
+                                                 int nvalid) {
     const int* base = colidx + begin;  // wave-uniform
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       const int r = rsub + p * RPP;
-      dst[p] = base[(unsigned)(r < nvalid ? r : nvalid - 1)];
+      dst[p] = base[(unsigned)(FULL ? r : (r < nvalid ? r : nvalid - 1))];
     }
   }
-  __device__ __forceinline__ void load_cols(const int* __restrict__ colidx, long long begin, int nvalid, int tid) {
-    load_cols_into(cols, colidx, begin, nvalid, tid);
+
+  // Gather of one stage: pass p loads VW consecutive features of factor row cols[p]; the
+  // rating of row (tid & 31) rides along.  Nothing here consumes a loaded value.
+  template <int P>
+  __device__ __forceinline__ void gather_pass(const float* __restrict__ gat, unsigned f4) {
+    const unsigned off = (unsigned)cols[P] * f4 + goff;  // bytes, < 4 GiB
+    v[P] = *reinterpret_cast<const VT*>(reinterpret_cast<const char*>(gat) + off);
   }
-  __device__ __forceinline__ void load_cols_next(const int* __restrict__ colidx, long long begin, int nvalid, int tid) {
-    load_cols_into(cols_nx, colidx, begin, nvalid, tid);
+  template <bool FULL>
+  __device__ __forceinline__ void gather_val(const float* __restrict__ val, long long begin, int nvalid, int tid) {
+    const int r = tid & (kStage - 1);
+    const float* vbase = val + begin;  // wave-uniform
+    rvv = vbase[(unsigned)(FULL ? r : (r < nvalid ? r : nvalid - 1))];
+  }
+  template <bool FULL>
+  __device__ __forceinline__ void gather(const float* __restrict__ val, const float* __restrict__ gat, unsigned f4,
+                                         long long begin, int nvalid, int tid) {
+    static_for<PASSES>([&](auto pc) { gather_pass<decltype(pc)::value>(gat, f4); });
+    gather_val<FULL>(val, begin, nvalid, tid);
+  }
+
+  // Full stage: feature lanes store their piece as loaded; other lanes hit the dummy slot.
+  template <int P>
+  __device__ __forceinline__ void store_pass_full(float* __restrict__ stage, float* __restrict__ dummy) const {
+    float* dst = feat ? stage + lds_row0 + P * RPP * LD : dummy;
+    *reinterpret_cast<VT*>(dst) = v[P];
+  }
+  __device__ __forceinline__ void store_val_full(float* __restrict__ stage, int f, int tid) const {
+    stage[(tid & (kStage - 1)) * LD + f] = rvv;  // 8 threads per row write the same value
+  }
+  // Ragged stage: rows [nvalid, nwrite) are written as zeros (nwrite = nvalid rounded up to 4).
+  template <int P>
+  __device__ __forceinline__ void store_pass_masked(float* __restrict__ stage, float* __restrict__ dummy, int nvalid,
+                                                    int nwrite) const {
+    const int r = rsub + P * RPP;
+    VT x = v[P];
+#pragma unroll
+    for (int e = 0; e < VW; ++e) x[e] = (r < nvalid) ? x[e] : 0.f;
+    float* dst = (feat && r < nwrite) ? stage + lds_row0 + P * RPP * LD : dummy;
+    *reinterpret_cast<VT*>(dst) = x;
+  }
+  __device__ __forceinline__ void store_val_masked(float* __restrict__ stage, float* __restrict__ dummy, int f,
+                                                   int nvalid, int nwrite, int tid) const {
+    const int r = tid & (kStage - 1);
+    float* dst = (r < nwrite) ? stage + r * LD + f : dummy;
+    *dst = (r < nvalid) ? rvv : 0.f;
+  }
+  __device__ __forceinline__ void store_masked(float* __restrict__ stage, float* __restrict__ dummy, int f, int nvalid,
+                                               int nwrite, int tid) const {
+    static_for<PASSES>([&](auto pc) { store_pass_masked<decltype(pc)::value>(stage, dummy, nvalid, nwrite); });
+    store_val_masked(stage, dummy, f, nvalid, nwrite, tid);
   }
   __device__ __forceinline__ void rotate_cols() {
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) cols[p] = cols_nx[p];
-  }
-
-  // Gather pass p: lane (row r, piece pc) loads VW consecutive features of factor row
-  // cols[p] (32-bit byte offset from the wave-uniform table base: factor tables are < 4 GiB,
-  // checked at launch).  Nothing here consumes a loaded value, so the loads stay in flight
-  // behind the MFMAs.  The rating rides in feature slot f; every lane of the row loads it
-  // (same address, one broadcast).  Padding is zeroed in store_pass().
-  template <int P>
-  __device__ __forceinline__ void gather_pass(const float* __restrict__ val, const float* __restrict__ gat, int f,
-                                              long long begin, int nvalid, int tid) {
-    const int pc = tid % LPR, rsub = tid / LPR;
-    const int col0 = pc * VW;
-    const unsigned col0c = col0 < f ? col0 : 0;
-    const int r = rsub + P * RPP;
-    const unsigned off = (unsigned)cols[P] * (unsigned)f + col0c;  // in floats
-    v[P] = *reinterpret_cast<const VT*>(gat + off);
-    const float* vbase = val + begin;  // wave-uniform
-    rv[P] = vbase[(unsigned)(r < nvalid ? r : nvalid - 1)];
-  }
-  __device__ __forceinline__ void gather(const float* __restrict__ val, const float* __restrict__ gat, int f,
-                                         long long begin, int nvalid, int tid) {
-    static_for<PASSES>([&](auto pc) { gather_pass<decltype(pc)::value>(val, gat, f, begin, nvalid, tid); });
-  }
-
-  // Store pass p.  Rows [nvalid, nwrite) are written as zeros (nwrite = nvalid rounded up
-  // to 4).  Lanes beyond the row pitch / rows beyond nwrite store to `dummy` instead.
-  template <int P>
-  __device__ __forceinline__ void store_pass(float* __restrict__ stage, float* __restrict__ dummy, int f, int nvalid,
-                                             int nwrite, int tid) const {
-    const int pc = tid % LPR, rsub = tid / LPR;
-    const int col0 = pc * VW;
-    const int r = rsub + P * RPP;
-    VT x = v[P];
-    const bool live = (r < nvalid) && (col0 < f);
-#pragma unroll
-    for (int e = 0; e < VW; ++e) x[e] = live ? x[e] : 0.f;
-    x[0] = (col0 == f && r < nvalid) ? rv[P] : x[0];
-    float* dst = (pc < PPR && r < nwrite) ? stage + r * Geo<NB>::LD + col0 : dummy;
-    *reinterpret_cast<VT*>(dst) = x;
-  }
-  __device__ __forceinline__ void store(float* __restrict__ stage, float* __restrict__ dummy, int f, int nvalid,
-                                        int nwrite, int tid) const {
-    static_for<PASSES>([&](auto pc) { store_pass<decltype(pc)::value>(stage, dummy, f, nvalid, nwrite, tid); });
   }
 };
 
@@ -621,6 +649,8 @@ __device__ __forceinline__ void item_body(float* smem, const KernelArgs& a, int 
   constexpr int NG = kStage / 4;  // MFMA groups of 4 ratings per full stage
   using St = Stager<NB, VT>;
   const int lane = tid & 63;
+  const int f = a.f;
+  const unsigned f4 = (unsigned)f * 4u;
   f32x4 acc[TPW];
 #pragma unroll
   for (int s = 0; s < TPW; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -629,35 +659,42 @@ __device__ __forceinline__ void item_body(float* smem, const KernelArgs& a, int 
   auto nvalid_of = [&](int s) { return (len - s * kStage) < kStage ? (len - s * kStage) : kStage; };
   auto begin_of = [&](int s) { return begin + (long long)s * kStage; };
   St st;
+  st.init(f, tid);
   // landing slot for masked-off stage stores: inside the read-ahead pad behind the two stage
   // buffers (read by nobody's MFMAs; in fused modes it is overwritten by G only after the
   // last barrier of the loop)
   float* dummy = smem + 2 * kStageFloats + 4 * LD + (tid & 15) * 4;
-  // Prologue: stage 0 into LDS buffer 0, stage 1 gathers in flight, column indices of stage 2.
+  // Prologue: padding zeroed, stage 0 into LDS buffer 0, stage 1 gathers in flight, column
+  // indices of stage 2.
   if (nstages > 0) {
     const int nv = nvalid_of(0);
-    st.load_cols(a.colidx, begin, nv, tid);
-    st.gather(a.val, a.gather, a.f, begin, nv, tid);
-    if (nstages > 1) st.load_cols(a.colidx, begin_of(1), nvalid_of(1), tid);
-    st.store(smem, dummy, a.f, nv, (nv + 3) & ~3, tid);
+    st.template load_cols_into<false>(st.cols, a.colidx, begin, nv);
+    st.zero_padding(smem, f, tid);
+    st.template gather<false>(a.val, a.gather, f4, begin, nv, tid);
+    if (nstages > 1) st.template load_cols_into<false>(st.cols_nx, a.colidx, begin_of(1), nvalid_of(1));
+    __syncthreads();  // padding zeros are in place before the (overlapping) rating stores
+    st.store_masked(smem, dummy, f, nv, (nv + 3) & ~3, tid);
     if (nstages > 1) {
-      st.gather(a.val, a.gather, a.f, begin_of(1), nvalid_of(1), tid);
-      if (nstages > 2) st.load_cols(a.colidx, begin_of(2), nvalid_of(2), tid);
+      st.rotate_cols();
+      st.template gather<false>(a.val, a.gather, f4, begin_of(1), nvalid_of(1), tid);
+      if (nstages > 2) st.template load_cols_into<false>(st.cols, a.colidx, begin_of(2), nvalid_of(2));
     }
   }
   __syncthreads();
 
   // Steady state.  Every stage but the last is full (32 ratings = NG groups).  While the
-  // MFMAs of group g drain through the matrix pipe the wave issues, in their shadow, one
-  // slice of the staging work: the LDS store of pass p of stage s+1 (gathered during stage
-  // s-1, so it has landed) immediately followed by the gather of pass p of stage s+2 into
-  // the same registers; after the last slice the column indices of stage s+3.
+  // MFMAs of group g drain through the matrix pipe the wave issues one slice of the staging
+  // work: the LDS store of pass p of stage s+1 (gathered during stage s-1, so it has landed)
+  // immediately followed by the gather of pass p of stage s+2 into the same registers; the
+  // column indices of stage s+3 go out with the first slice.
   const float* rowbase = smem + (lane >> 4) * LD + (lane & 15);
   auto load_blk = [&](float (&blk)[NB], const float* p) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) blk[b] = p[16 * b];
   };
-  for (int s = 0; s + 1 < nstages; ++s) {
+  // TARGET_FULL: stage s+1 (the one being stored) holds 32 ratings -> select-free stores.
+  auto stage_body = [&](auto fullc, int s) {
+    constexpr bool TARGET_FULL = decltype(fullc)::value;
     const float* cur = rowbase + (s & 1) * kStageFloats;
     float* nxt = smem + ((s + 1) & 1) * kStageFloats;
     const int nv1 = nvalid_of(s + 1), nw1 = (nv1 + 3) & ~3;
@@ -680,18 +717,28 @@ __device__ __forceinline__ void item_body(float* smem, const KernelArgs& a, int 
       static_for<St::PASSES>([&](auto pc) {
         constexpr int p = decltype(pc)::value;
         if constexpr (p * NG / St::PASSES == g) {
-          st.template store_pass<p>(nxt, dummy, a.f, nv1, nw1, tid);
-          st.template gather_pass<p>(a.val, a.gather, a.f, b2, nv2, tid);
+          if constexpr (TARGET_FULL)
+            st.template store_pass_full<p>(nxt, dummy);
+          else
+            st.template store_pass_masked<p>(nxt, dummy, nv1, nw1);
+          st.template gather_pass<p>(a.gather, f4);
         }
       });
-      if constexpr (g == 0) st.load_cols_next(a.colidx, b3, nv3, tid);  // consumed a whole stage later
-      // (threading the slice between the seven MFMAs with sched_group_barrier measured ~3 %
-      //  slower than issuing it after them: tools/mfma_ladder.hip, F=63 vs F=127)
+      if constexpr (g == NG - 1) {  // all passes stored: the rating register is free again
+        if constexpr (TARGET_FULL)
+          st.store_val_full(nxt, f, tid);
+        else
+          st.store_val_masked(nxt, dummy, f, nv1, nw1, tid);
+        st.template gather_val<false>(a.val, b2, nv2, tid);
+      }
+      if constexpr (g == 0) st.template load_cols_into<false>(st.cols_nx, a.colidx, b3, nv3);  // used a stage later
       __builtin_amdgcn_sched_barrier(0);
     });
     st.rotate_cols();
     __syncthreads();
-  }
+  };
+  for (int s = 0; s + 2 < nstages; ++s) stage_body(std::true_type{}, s);
+  if (nstages > 1) stage_body(std::false_type{}, nstages - 2);  // its target is the (ragged) last stage
   if (nstages > 0) {
     const int sl = nstages - 1;
     mma_stage<NB, W>(smem + (sl & 1) * kStageFloats, acc, (nvalid_of(sl) + 3) >> 2, lane);

@@ -5,6 +5,8 @@
 //   F & 16: gathered data is what gets stored (one stage later), like the real kernel
 //   F & 32: column indices loaded one stage ahead (else the same index every stage)
 //   F & 64: sched_group_barrier interleave of the slice with the MFMAs
+//   F & 128: 'strip' variant: 5 MFMAs per group + 1 shared tile every 4th group + 10 DPP-broadcast
+//            VALU FMAs per group (models moving the 5-column tail block off the matrix pipe)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -22,6 +24,8 @@ __global__ __launch_bounds__(256) void k(float* out, const float* __restrict__ t
   for (auto& a : acc) a = f32x4{0, 0, 0, 0};
   f32x4 v[4];
   for (auto& x : v) x = f32x4{0, 0, 0, 0};
+  float strip[10];
+  for (auto& x : strip) x = 0.f;
   const int pc = tid & 31, rsub = tid >> 5;
   const int* myidx = idx + (size_t)blockIdx.x * stages * 32;
   int cols[4], cols_nx[4];
@@ -44,8 +48,19 @@ __global__ __launch_bounds__(256) void k(float* out, const float* __restrict__ t
       acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1, b2, acc[2], 0, 0, 0);
       acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1, b3, acc[3], 0, 0, 0);
       acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(b2, b2, acc[4], 0, 0, 0);
-      acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(b2, b3, acc[5], 0, 0, 0);
-      acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(b3, b3, acc[6], 0, 0, 0);
+      if (!(F & 128)) {
+        acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(b2, b3, acc[5], 0, 0, 0);
+        acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(b3, b3, acc[6], 0, 0, 0);
+      } else {
+        if ((g & 3) == (tid >> 6)) acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(b2, b3, acc[5], 0, 0, 0);
+#define STRIP_A(a)                                                                                              \
+  {                                                                                                             \
+    const float ba = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b3), 0x150 + a, 0xf, 0xf, false)); \
+    strip[a] = fmaf(b0, ba, strip[a]);                                                                          \
+    strip[5 + a] = fmaf(b1, ba, strip[5 + a]);                                                                  \
+  }
+        STRIP_A(0) STRIP_A(1) STRIP_A(2) STRIP_A(3) STRIP_A(4)
+      }
       if (!(F & 64)) __builtin_amdgcn_sched_barrier(0);
       if ((g & 1) == 0) {
         const int p = g >> 1;
@@ -80,6 +95,7 @@ __global__ __launch_bounds__(256) void k(float* out, const float* __restrict__ t
   float sum = 0;
   for (auto& a : acc) sum += a[0] + a[1] + a[2] + a[3];
   for (auto& x : v) sum += x[0];
+  for (auto& x : strip) sum += x;
   out[blockIdx.x * 256 + tid] = sum;
 }
 
@@ -98,7 +114,7 @@ void run(float* d, float* table, int* idx, int wgs_per_cu, int stages) {
     hipEventSynchronize(e1);
     hipEventElapsedTime(&ms, e0, e1);
   }
-  const double flops = (double)grid * 4 * stages * 8 * 7 * 2048.0;
+  const double flops = (double)grid * 4 * stages * 8 * 7 * 2048.0;  // nominal (7 tiles/group) so that times compare
   printf("F=%3d wgs/cu=%d  %.3f ms  %.1f TFLOP/s\n", F, wgs_per_cu, ms, flops / ms / 1e9);
 }
 
@@ -124,7 +140,7 @@ int main() {
     run<15>(d, table, idx, w, stages);   // gathers issued, 1 dword consumed
     run<31>(d, table, idx, w, stages);   // full 16 B consumed a stage later (same row each stage)
     run<63>(d, table, idx, w, stages);   // + random rows with prefetched indices
-    run<63 + 64>(d, table, idx, w, stages);
+    run<63 + 128>(d, table, idx, w, stages);
   }
   return 0;
 }
