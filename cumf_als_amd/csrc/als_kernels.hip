@@ -124,14 +124,15 @@ struct Stager {
     lds_row0 = rsub * LD + col0;
   }
 
-  // Zero the padding of both stage buffers: columns [f, LD) of every row (the rating slot f
-  // is overwritten per stage).  Needed once per item (the solvers' G aliases the buffers).
+  // Zero the padding of both stage buffers: columns [f + VW, LD) of every row (the piece at
+  // column f carries the rating and is rewritten whole per stage).  Needed once per item (the
+  // solvers' G aliases the buffers).
   __device__ __forceinline__ void zero_padding(float* __restrict__ smem, int f, int tid) const {
-    const int pad = LD - f;  // floats per row, a multiple of VW
-    for (int e = tid; e < 2 * kStage * (pad / VW); e += kThreads) {
-      const int row = e / (pad / VW), k = e - row * (pad / VW);
+    const int pieces = (LD - f) / VW - 1;  // per row
+    for (int e = tid; e < 2 * kStage * pieces; e += kThreads) {
+      const int row = e / pieces, k = e - row * pieces;
       VT z = {};
-      *reinterpret_cast<VT*>(smem + row * LD + f + k * VW) = z;
+      *reinterpret_cast<VT*>(smem + row * LD + f + (k + 1) * VW) = z;
     }
   }
 
@@ -173,7 +174,9 @@ struct Stager {
     *reinterpret_cast<VT*>(dst) = v[P];
   }
   __device__ __forceinline__ void store_val_full(float* __restrict__ stage, int f, int tid) const {
-    stage[(tid & (kStage - 1)) * LD + f] = rvv;  // 8 threads per row write the same value
+    VT x = {};
+    x[0] = rvv;  // the whole piece {rating, 0, ...}; 8 threads per row write the same value
+    *reinterpret_cast<VT*>(stage + (tid & (kStage - 1)) * LD + f) = x;
   }
   // Ragged stage: rows [nvalid, nwrite) are written as zeros (nwrite = nvalid rounded up to 4).
   template <int P>
@@ -190,7 +193,9 @@ struct Stager {
                                                    int nvalid, int nwrite, int tid) const {
     const int r = tid & (kStage - 1);
     float* dst = (r < nwrite) ? stage + r * LD + f : dummy;
-    *dst = (r < nvalid) ? rvv : 0.f;
+    VT x = {};
+    x[0] = (r < nvalid) ? rvv : 0.f;
+    *reinterpret_cast<VT*>(dst) = x;
   }
   __device__ __forceinline__ void store_masked(float* __restrict__ stage, float* __restrict__ dummy, int f, int nvalid,
                                                int nwrite, int tid) const {
@@ -672,7 +677,6 @@ __device__ __forceinline__ void item_body(float* smem, const KernelArgs& a, int 
     st.zero_padding(smem, f, tid);
     st.template gather<false>(a.val, a.gather, f4, begin, nv, tid);
     if (nstages > 1) st.template load_cols_into<false>(st.cols_nx, a.colidx, begin_of(1), nvalid_of(1));
-    __syncthreads();  // padding zeros are in place before the (overlapping) rating stores
     st.store_masked(smem, dummy, f, nv, (nv + 3) & ~3, tid);
     if (nstages > 1) {
       st.rotate_cols();
