@@ -78,6 +78,7 @@ int cumf_plan_info(const cumf_plan_t* plan, long info[4]);
  * colidx/val: DEVICE CSR arrays of the whole matrix (indexed by the plan's row
  * pointers); gather: DEVICE factors gathered from (cols x f); update: DEVICE
  * factors being solved (rows x f), read as the CG warm start and overwritten.
+ * `gather` must be smaller than 4 GiB (32-bit byte offsets in the gather: 10.7 M rows at f = 100).
  */
 int cumf_als_update_fused(const cumf_plan_t* plan, const int* colidx, const float* val,
                           const float* gather, float* update, int f, float lambda, int solver,
