@@ -24,10 +24,15 @@ __host__ __device__ constexpr int solve_ldg(int f, int mode) { return mode == kM
 __host__ __device__ constexpr size_t solve_g_floats(int f, int mode) {
   return ((size_t)f * solve_ldg(f, mode) + 3) & ~(size_t)3;
 }
+// Register LU (fast path): packed upper-triangular row store (als_kernels.hip: lu_row_off) + f
+// pivot reciprocals.  f = 100: 29 520 B, below the 32 256 B of the stage buffers it aliases
+// -> 5 workgroups per CU.
+__host__ __device__ constexpr size_t lu_packed_floats(int nb) { return (size_t)256 * nb * (nb + 1) / 2 + 16 * nb; }
+__host__ __device__ constexpr size_t lu_lds_floats(int nb, int f) { return lu_packed_floats(nb) + (size_t)((f + 3) & ~3); }
 constexpr int kCgExtraFloats = 12 * kVecLd;  // 4 per-wave operand copies + 2 x 4 partial mat-vecs
-// whole LDS footprint of a solve: G + CG exchange buffers | G + pivot reciprocals (fast LU)
+// whole LDS footprint of a solve on a full G: G + CG exchange buffers | G (exact-order LU)
 __host__ __device__ constexpr size_t solve_lds_floats(int f, int mode) {
-  return solve_g_floats(f, mode) + (mode == kModeCG ? (size_t)kCgExtraFloats : (mode == kModeLU ? (size_t)((f + 3) & ~3) : 0));  // LU: + f pivot reciprocals (f = 100: 40 800 B -> 4 workgroups per CU)
+  return solve_g_floats(f, mode) + (mode == kModeCG ? (size_t)kCgExtraFloats : 0);
 }
 
 struct KernelArgs {

@@ -35,6 +35,14 @@ namespace cumf {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef CUMF_LU_ABL
+#define CUMF_LU_ABL 0
+#endif
+#ifndef CUMF_LU_PANEL
+#define CUMF_LU_PANEL 1
+#endif
+constexpr int kLuPanel = CUMF_LU_PANEL;  // pivots per barrier in the register-resident LU
+
 // ----------------------------------------------------------------------------------
 // Geometry of one workgroup (256 threads = 4 waves) for NB 16-wide feature blocks.
 // ----------------------------------------------------------------------------------
@@ -258,6 +266,48 @@ __device__ __forceinline__ void mma_stage(const float* __restrict__ stage, f32x4
     rowp += 8 * LD;
   }
   if (g < ngroups) mma_group<NB, W>(blk_a, acc);
+}
+
+// Packed row store of the register LU: block row kb (rows 16 kb .. 16 kb + 15) keeps columns
+// 16 kb .. 16 NB - 1 only, at an odd pitch (the back substitution walks columns).  For NB = 7
+// that is 7 280 floats instead of the 10 100 of a full f x (f + 1) matrix, which is what lets
+// a fifth workgroup share the CU.
+template <int NB>
+__host__ __device__ constexpr int lu_row_pitch(int kb) { return 16 * (NB - kb) + 1; }
+template <int NB>
+__host__ __device__ constexpr int lu_block_off(int kb) { return 256 * (kb * NB - kb * (kb - 1) / 2) + 16 * kb; }
+// offset of the (virtual) element (k, 0); valid for columns j >= 16 * (k >> 4)
+template <int NB>
+__device__ __forceinline__ int lu_row_off(int k) {
+  const int kb = k >> 4, kk = k & 15;
+  return 256 * (kb * NB - ((kb * (kb - 1)) >> 1)) + kk * (16 * (NB - kb) + 1);
+}
+template <int NB>
+__host__ __device__ constexpr int tile_of(int I, int J) { return I * NB - I * (I - 1) / 2 + (J - I); }
+// row m of a 16 x 16 tile parked in LDS sits at slot 4 * (m & 3) + (m >> 2): the accumulator
+// store (lane group kk writes rows 4 kk + r) then spreads over all 32 banks.
+__device__ __forceinline__ int tiled_row(int m) { return 4 * (m & 3) + (m >> 2); }
+
+// Accumulator tiles -> LDS, tile-major ([tile][16][16], rows permuted by tiled_row): the
+// hand-over to lu_solve_reg, whose threads pick their elements up with TileLoad.
+template <int NB, int W>
+__device__ __forceinline__ void tiles_to_tiled(const f32x4 (&acc)[Geo<NB>::TPW], float* __restrict__ T,
+                                               float reg, int lane) {
+  constexpr int NT = Geo<NB>::NT, TPW = Geo<NB>::TPW;
+  const int c = lane & 15, kk = lane >> 4;
+  static_for<TPW>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    constexpr int t = W * TPW + s;
+    if constexpr (t < NT) {
+      constexpr int I = tile_I<NB>(t), J = tile_J<NB>(t);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[s][r];
+        if (I == J && 4 * kk + r == c) v += reg;  // lambda * n_u on the diagonal (als.cu:545-557)
+        T[256 * t + (4 * r + kk) * 16 + c] = v;
+      }
+    }
+  });
 }
 
 // Accumulator tile -> LDS system matrix G (f x ldg, column f = RHS).  C/D layout of
@@ -524,89 +574,302 @@ __device__ __forceinline__ void lu_solve_lds(float* __restrict__ G, int ldg, int
   if (tid < 64) back_substitute_lds<false, 4>(G, ldg, f, nullptr, x_global, tid);
 }
 
-// Register-resident symmetric elimination (the fast LU path, f <= 128).
+// Back substitution of the register LU, U x = y with the reciprocals of the diagonal in rdiag
+// (wave 0).  The recurrence is a chain of f dependent steps, so everything that does not depend
+// on the running vector is moved off it: row i is pre-scaled by 1/u_ii (z_i = y_i / u_ii,
+// v_ik = u_ik / u_ii: unit diagonal, x_k = z_k needs no multiply), the column of step k is
+// fetched kBackDepth steps ahead, masked (rows >= k -> 0) and scaled when it arrives, and the
+// pivots of rows 64.. and 0..63 get their own passes so the readlane register is static.  What
+// is left on the chain per step is one v_readlane and one v_fma.
+constexpr int kBackDepth = 4;
+template <int NB, int NQ>
+__device__ __forceinline__ void back_substitute_fast(const float* __restrict__ U, int f,
+                                                     const float* __restrict__ rdiag,
+                                                     float* __restrict__ x_global, int lane) {
+  float z[NQ], rdl[NQ];
+  const float* rowp[NQ];
+  static_for<NQ>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    const int i = lane + 64 * q;
+    const int ic = i < f ? i : f - 1;
+    rowp[q] = U + lu_row_off<NB>(ic);
+    rdl[q] = i < f ? rdiag[ic] : 0.f;
+    z[q] = rowp[q][f] * rdl[q];
+  });
+  static_for<NQ>([&](auto pc) {
+    constexpr int Q = NQ - 1 - decltype(pc)::value;  // pivots 64Q .. 64Q+63 live in z[Q]
+    const int klo = 64 * Q;
+    const int top = (f - 1 < klo + 63) ? f - 1 : klo + 63;
+    if (top >= klo) {
+      // whole double-groups of 2 x kBackDepth steps, no guards in the loop (a guard is a branch,
+      // and branches make the compiler wait for every outstanding LDS read): the steps above
+      // f-1 that round the count up are no-ops (their column is masked to 0).  While one group
+      // of columns is consumed the other is in flight; the sched_barriers keep the compiler
+      // from sinking the reads next to their use.
+      constexpr int D2 = 2 * kBackDepth;
+      const int khi = klo + ((top - klo + D2) / D2) * D2 - 1;
+      float c[2][kBackDepth][Q + 1];
+      auto issue = [&](auto hc, int kfirst) {  // columns kfirst, kfirst-1, ... into half h
+        constexpr int h = decltype(hc)::value;
+        static_for<kBackDepth>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          const int kc = kfirst - j > 0 ? kfirst - j : 0;
+          static_for<Q + 1>([&](auto qc) { c[h][j][decltype(qc)::value] = rowp[decltype(qc)::value][kc]; });
+        });
+      };
+      auto consume = [&](auto hc, int kfirst) {
+        constexpr int h = decltype(hc)::value;
+        static_for<kBackDepth>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          const int kk = kfirst - j;
+          const int lim = kk < f ? kk : 0;  // rows below the pivot take part; none for a padding step
+          float v[Q + 1];
+          static_for<Q + 1>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            v[q] = (lane + 64 * q < lim) ? c[h][j][q] * rdl[q] : 0.f;
+          });
+          const float xk = __builtin_bit_cast(
+              float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z[Q]), kk & 63));
+          static_for<Q + 1>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            z[q] = fmaf(-v[q], xk, z[q]);
+          });
+        });
+      };
+      issue(std::integral_constant<int, 0>{}, khi);
+      issue(std::integral_constant<int, 1>{}, khi - kBackDepth);
+      __builtin_amdgcn_sched_barrier(0);
+      for (int k = khi; k >= klo; k -= D2) {
+        consume(std::integral_constant<int, 0>{}, k);
+        issue(std::integral_constant<int, 0>{}, k - D2);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(std::integral_constant<int, 1>{}, k - kBackDepth);
+        issue(std::integral_constant<int, 1>{}, k - D2 - kBackDepth);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  });
+  static_for<NQ>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    if (lane + 64 * q < f) x_global[lane + 64 * q] = z[q];
+  });
+}
+
+// Register-resident symmetric elimination (the fast LU path, f <= 200), M pivots per barrier.
 // The upper triangle of [A | b] is spread over the 16 x 16 thread grid, element (i, j) in
-// thread (i & 15, j & 15), register block (i >> 4, j >> 4).  Step k: the 16 threads
-// owning row k publish it to LDS row k of G (it is the final row k of U), one barrier,
-// every thread reads the <= 2*NB + 1 entries it needs and updates its registers:
-//     a_ij -= (u_ki / u_kk) * u_kj      (i > k, j >= i; column k of the symmetric Schur
-//                                         complement is read from row k)
-// i.e. Gaussian elimination without pivoting restricted to the upper triangle
-// (U = D L^T of the same A = L U).  Half the multiply-adds of lu_solve_lds, one LDS
-// broadcast row and one barrier per pivot instead of a full LDS sweep.
-template <int NB>
-__device__ __forceinline__ void lu_solve_reg(float* __restrict__ G, int ldg, int f, float* __restrict__ rdiag,
+// thread (i & 15, j & 15), register block (i >> 4, j >> 4); `load(bi, bj)` fetches this
+// thread's element of block (bi, bj) (from the accumulator tiles parked in LDS, or from
+// global memory).  Pivots are processed in panels of M consecutive rows:
+//   1. the thread rows owning the M panel rows publish them (as they stand, i.e. updated by
+//      all earlier panels) to the packed row store U (lu_row_off); ONE barrier;
+//   2. every thread reads the panel at its own row / column positions plus the M x M pivot
+//      block and eliminates the panel IN REGISTERS, redundantly (row r loses its
+//      projections on rows 0..r-1 of the panel): no further communication;
+//   3. rank-M update of the thread's registers  a_ij -= sum_r (u_ri / u_rr) * u_rj  (i > row r);
+//   4. the final values of panel rows 1..M-1 are written back to U by wave 0 after the NEXT
+//      barrier (by then nobody reads the published, un-eliminated copies any more).
+// This is Gaussian elimination without pivoting restricted to the upper triangle (U = D L^T of
+// A = L U).  Measured (tools/lu_variants.sh): M = 2 halves the barriers and is not faster, the
+// step is bound by LDS reads + VALU, so M = 1 is the default.
+// U may alias the memory `load` reads from: all loads complete before the first publish.
+template <int NB, int M, typename Load>
+__device__ __forceinline__ void lu_solve_reg(Load load, float* __restrict__ U, int f, float* __restrict__ rdiag,
                                              float* __restrict__ x_global, int tid) {
+  static_assert(M == 1 || M == 2 || M == 4, "panel height");
   const int ti = tid >> 4, tj = tid & 15;
   float a[NB][NB];
   static_for<NB>([&](auto bic) {
     constexpr int bi = decltype(bic)::value;
     static_for<NB>([&](auto bjc) {
       constexpr int bj = decltype(bjc)::value;
-      if constexpr (bj >= bi) {
-        const int i = 16 * bi + ti, j = 16 * bj + tj;
-        const float v = G[(i < f ? i : f - 1) * ldg + (j <= f ? j : f)];
-        a[bi][bj] = (i < f && j <= f) ? v : 0.f;
-      }
+      if constexpr (bj >= bi) a[bi][bj] = load(bic, bjc, ti, tj);
     });
   });
   __syncthreads();
-  // Rows >= f and columns > f of the register image are padding: they are never published
-  // and never read back, so the updates below run on them unmasked (whatever lands there
-  // is dead).  Row-k reads past column f stay inside the LDS allocation (G is followed by
-  // rdiag) and only feed those dead registers.
+  // Rows >= f and columns > f of the register image are padding: never published, never read
+  // back, so updates run on them unmasked (whatever lands there is dead).  Panel reads of
+  // padding positions stay inside the row store and only feed dead registers.
+  const bool last_col_ok = 16 * (NB - 1) + tj <= f;
+  float fin[M > 1 ? M - 1 : 1][NB];  // final panel rows 1..M-1 of the previous panel at this thread's columns
+  int fin_k0 = -1;
+  auto write_fin = [&]() {  // wave 0, thread rows 1..M-1: row fin_k0 + ti
+    if (M > 1 && fin_k0 >= 0 && tid < 64 && ti >= 1 && ti < M && fin_k0 + ti < f) {
+      float* w = U + lu_row_off<NB>(fin_k0 + ti) + tj;
+      const int kbp = fin_k0 >> 4;
+      static_for<NB>([&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        float v = fin[0][b];
+        static_for<(M > 1 ? M - 1 : 1)>([&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          v = (ti == r + 1) ? fin[r][b] : v;
+        });
+        if constexpr (b < NB - 1) {
+          if (b >= kbp) w[16 * b] = v;
+        }
+        if constexpr (b == NB - 1) {
+          if (last_col_ok) w[16 * b] = v;
+        }
+      });
+    }
+  };
+
   static_for<NB>([&](auto kbc) {
     constexpr int kb = decltype(kbc)::value;
-    const float* urow_i = G + (16 * kb) * ldg + ti;  // + kk * ldg + 16 * b
-    const float* urow_j = G + (16 * kb) * ldg + tj;
-    for (int kk = 0; kk < 16; ++kk) {
-      const int k = 16 * kb + kk;
-      if (k >= f) break;
-      if (ti == kk) {  // this thread row owns pivot row k: publish it (= final row k of U)
-        float* urow_w = G + k * ldg + tj;
+    constexpr int pitch = lu_row_pitch<NB>(kb);
+    float* blk = U + lu_block_off<NB>(kb) - 16 * kb;  // element (16 kb, 0) of this block row
+    for (int q = 0; q < 16 / M; ++q) {
+      const int kk0 = q * M;
+      const int k0 = 16 * kb + kk0;
+      if (k0 >= f) break;
+      // 1. publish: thread rows kk0 .. kk0+M-1 own the panel rows
+      if (ti >= kk0 && ti < kk0 + M && 16 * kb + ti < f) {
+        float* w = blk + ti * pitch + tj;
         static_for<NB>([&](auto bjc) {
           constexpr int bj = decltype(bjc)::value;
-          // blocks below NB-1 lie entirely left of column f (NB = f/16 + 1): no predicate
-          if constexpr (bj >= kb && bj < NB - 1) urow_w[16 * bj] = a[kb][bj];
+          if constexpr (bj >= kb && bj < NB - 1) w[16 * bj] = a[kb][bj];
           if constexpr (bj >= kb && bj == NB - 1) {
-            if (16 * bj + tj <= f) urow_w[16 * bj] = a[kb][bj];
+            if (last_col_ok) w[16 * bj] = a[kb][bj];
           }
         });
       }
       __syncthreads();
-      // all reads unconditional and issued together: one LDS latency per pivot
-      float ui[NB], uj[NB];
-      const float piv = G[k * ldg + k];
-      static_for<NB>([&](auto bc) {
-        constexpr int b = decltype(bc)::value;
-        if constexpr (b >= kb) {
-          ui[b] = urow_i[16 * b];
-          uj[b] = urow_j[16 * b];
+      write_fin();  // previous panel's final rows (no one reads their published copies any more)
+      // 2. read the panel; all reads unconditional and issued together
+      float ui[M][NB], uj[M][NB], P[M][M];
+      static_for<M>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        // a short last panel (f odd multiple of M) re-reads its first row; masked below
+        const float* urow = blk + ((k0 + r < f) ? kk0 + r : kk0) * pitch;
+        static_for<NB>([&](auto bc) {
+          constexpr int b = decltype(bc)::value;
+          if constexpr (b >= kb) {
+            ui[r][b] = urow[16 * b + ti];
+            uj[r][b] = urow[16 * b + tj];
+          }
+        });
+        static_for<M>([&](auto cc) {
+          constexpr int c = decltype(cc)::value;
+          if constexpr (c >= r) P[r][c] = urow[k0 + c];
+        });
+      });
+      bool valid[M];
+      static_for<M>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        valid[r] = k0 + r < f;
+        if constexpr (r > 0) {
+          static_for<NB>([&](auto bc) {
+            constexpr int b = decltype(bc)::value;
+            if constexpr (b >= kb) {
+              ui[r][b] = valid[r] ? ui[r][b] : 0.f;
+              uj[r][b] = valid[r] ? uj[r][b] : 0.f;
+            }
+          });
+          static_for<M>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            if constexpr (c >= r) P[r][c] = valid[r] ? P[r][c] : (c == r ? 1.f : 0.f);
+          });
         }
       });
-      float rp = __builtin_amdgcn_rcpf(piv);
-      rp = fmaf(fmaf(-piv, rp, 1.0f), rp, rp);  // one Newton step: 1/piv to ~1 ulp
-      if (tid == 0) rdiag[k] = rp;
-      float li[NB];
-      static_for<NB>([&](auto bc) {
-        constexpr int b = decltype(bc)::value;
-        if constexpr (b > kb) li[b] = -ui[b] * rp;
-        if constexpr (b == kb) li[b] = (ti > kk) ? -ui[b] * rp : 0.f;  // rows <= k of the pivot block are final
+      // in-register elimination of the panel
+      float rp[M];
+      static_for<M>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        static_for<M>([&](auto qc) {
+          constexpr int q2 = decltype(qc)::value;
+          if constexpr (q2 < r) {
+            const float m = -P[q2][r] * rp[q2];  // -(multiplier of row r w.r.t. pivot q2)
+            static_for<M>([&](auto cc) {
+              constexpr int c = decltype(cc)::value;
+              if constexpr (c >= r) P[r][c] = fmaf(m, P[q2][c], P[r][c]);
+            });
+            static_for<NB>([&](auto bc) {
+              constexpr int b = decltype(bc)::value;
+              if constexpr (b >= kb) {
+                ui[r][b] = fmaf(m, ui[q2][b], ui[r][b]);
+                uj[r][b] = fmaf(m, uj[q2][b], uj[r][b]);
+              }
+            });
+          }
+        });
+        float t = __builtin_amdgcn_rcpf(P[r][r]);
+        rp[r] = fmaf(fmaf(-P[r][r], t, 1.0f), t, t);  // one Newton step: 1/pivot to ~1 ulp
+      });
+      if (tid == 0) {
+        static_for<M>([&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          if (valid[r]) rdiag[k0 + r] = rp[r];
+        });
+      }
+      // 3. multipliers (in place of ui) and the rank-M update
+      static_for<M>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        static_for<NB>([&](auto bc) {
+          constexpr int b = decltype(bc)::value;
+          if constexpr (b > kb) ui[r][b] = valid[r] ? -ui[r][b] * rp[r] : 0.f;
+          if constexpr (b == kb) ui[r][b] = (valid[r] && ti > kk0 + r) ? -ui[r][b] * rp[r] : 0.f;
+        });
       });
       static_for<NB>([&](auto bic) {
         constexpr int bi = decltype(bic)::value;
         static_for<NB>([&](auto bjc) {
           constexpr int bj = decltype(bjc)::value;
-          if constexpr (bi >= kb && bj >= bi) a[bi][bj] = fmaf(li[bi], uj[bj], a[bi][bj]);
+          if constexpr (bi >= kb && bj >= bi) {
+            static_for<M>([&](auto rc) {
+              constexpr int r = decltype(rc)::value;
+              a[bi][bj] = fmaf(ui[r][bi], uj[r][bj], a[bi][bj]);
+            });
+          }
         });
       });
-      urow_i += ldg;
-      urow_j += ldg;
+      // 4. remember the final panel rows 1..M-1
+      if constexpr (M > 1) {
+        static_for<M - 1>([&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          static_for<NB>([&](auto bc) {
+            constexpr int b = decltype(bc)::value;
+            if constexpr (b >= kb) fin[r][b] = uj[r + 1][b];
+          });
+        });
+        fin_k0 = k0;
+      }
     }
   });
   __syncthreads();
-  if (tid < 64) back_substitute_lds<true, (16 * NB + 63) / 64>(G, ldg, f, rdiag, x_global, tid);
+  if constexpr (M > 1) {
+    write_fin();
+    __syncthreads();
+  }
+  if (tid < 64) back_substitute_fast<NB, (16 * NB + 63) / 64>(U, f, rdiag, x_global, tid);
 }
+
+// Loaders of lu_solve_reg.  TileLoad: the accumulator tiles parked in LDS by tiles_to_tiled.
+template <int NB>
+struct TileLoad {
+  const float* T;
+  int f;
+  template <typename BI, typename BJ>
+  __device__ __forceinline__ float operator()(BI, BJ, int ti, int tj) const {
+    constexpr int bi = BI::value, bj = BJ::value;
+    const int i = 16 * bi + ti, j = 16 * bj + tj;
+    const float v = T[256 * tile_of<NB>(bi, bj) + tiled_row(ti) * 16 + tj];
+    return (i < f && j <= f) ? v : 0.f;
+  }
+};
+// GlobalLoad: a row-major f x f matrix and its right-hand side in global memory.
+template <int NB>
+struct GlobalLoad {
+  const float* A;
+  const float* b;
+  int f;
+  template <typename BI, typename BJ>
+  __device__ __forceinline__ float operator()(BI, BJ, int ti, int tj) const {
+    constexpr int bi = BI::value, bj = BJ::value;
+    const int i = 16 * bi + ti, j = 16 * bj + tj;
+    const int ic = i < f ? i : f - 1;
+    const float v = (j < f) ? A[(size_t)ic * f + j] : b[ic];
+    return (i < f && j <= f) ? v : 0.f;
+  }
+};
 
 // ----------------------------------------------------------------------------------
 // Row epilogue.  dump_row<W> is per-wave (tile layout); solve_row is common to all waves.
@@ -622,8 +885,11 @@ __device__ __forceinline__ void dump_row(const f32x4 (&acc)[Geo<NB>::TPW], float
     float* rhs = a.rhs ? a.rhs + (size_t)(row - a.row_begin) * f : nullptr;
     tiles_to_global<NB, W>(acc, tt, rhs, f, reg, lane);
   } else {
-    // G aliases the stage buffers (all MFMA reads are done)
-    tiles_to_lds<NB, W>(acc, smem, solve_ldg(f, MODE), f, (float)rowlen * a.lambda, lane);
+    // G / the tile store aliases the stage buffers (all MFMA reads are done)
+    if constexpr (MODE == kModeLU)
+      tiles_to_tiled<NB, W>(acc, smem, (float)rowlen * a.lambda, lane);
+    else
+      tiles_to_lds<NB, W>(acc, smem, solve_ldg(f, MODE), f, (float)rowlen * a.lambda, lane);
   }
 }
 
@@ -637,7 +903,7 @@ __device__ __forceinline__ void solve_row(float* smem, const KernelArgs& a, int 
     if constexpr (MODE == kModeCG)
       cg_solve_lds<NB>(G, ldg, f, smem + solve_g_floats(f, MODE), x, a.cg_iters, tid);
     else
-      lu_solve_reg<NB>(G, ldg, f, smem + solve_g_floats(f, MODE), x, tid);
+      lu_solve_reg<NB, kLuPanel>(TileLoad<NB>{smem, f}, smem, f, smem + lu_packed_floats(NB), x, tid);
   }
 }
 
@@ -816,9 +1082,14 @@ __global__ __launch_bounds__(kThreads) void solve_lds_kernel(const float* __rest
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
   const size_t sys = blockIdx.x;
+  const float* As = A + sys * (size_t)f * f;
+  if constexpr (NB != 0 && MODE == kModeLU) {
+    lu_solve_reg<NB, kLuPanel>(GlobalLoad<NB>{As, b + sys * f, f}, smem, f, smem + lu_packed_floats(NB), x + sys * f,
+                               tid);
+    return;
+  }
   const int ldg = solve_ldg(f, MODE);
   float* G = smem;
-  const float* As = A + sys * (size_t)f * f;
   for (int e = tid; e < f * f; e += kThreads) {
     const int i = e / f, j = e - i * f;
     G[i * ldg + j] = As[e];
@@ -829,8 +1100,6 @@ __global__ __launch_bounds__(kThreads) void solve_lds_kernel(const float* __rest
     lu_solve_lds(G, ldg, f, x + sys * f, tid);
   else if constexpr (MODE == kModeCG)
     cg_solve_lds<NB>(G, ldg, f, smem + solve_g_floats(f, MODE), x + sys * f, cg_iters, tid);
-  else
-    lu_solve_reg<NB>(G, ldg, f, smem + solve_g_floats(f, MODE), x + sys * f, tid);
 }
 
 // CG with A streamed from global memory every mat-vec, for f too large for an
@@ -975,7 +1244,7 @@ static hipError_t launch_nb(const KernelArgs& a, long n_items, long n_mrows, hip
   const size_t stage_floats = (2 * (size_t)kStage + 8) * Geo<NB>::LD;  // + read-ahead pad of mma_stage
   size_t floats = stage_floats;
   if (MODE != kModeMaterialize) {
-    const size_t solve = solve_lds_floats(a.f, MODE);
+    const size_t solve = MODE == kModeLU ? lu_lds_floats(NB, a.f) : solve_lds_floats(a.f, MODE);
     floats = floats > solve ? floats : solve;
   }
   static const size_t lds_pad = getenv("CUMF_ALS_LDS_PAD") ? (size_t)atol(getenv("CUMF_ALS_LDS_PAD")) : 0;  // occupancy experiments
@@ -1027,19 +1296,45 @@ static hipError_t launch_mode(const KernelArgs& a, int mode, long n_items, long 
 hipError_t launch_half_iteration(const KernelArgs& a, int mode, long n_items, long n_mrows, hipStream_t stream) {
   const int nb = nb_for_f(a.f);
   switch (nb) {
+#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 1
     case 1: return launch_mode<1>(a, mode, n_items, n_mrows, stream);
+#endif
+#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 2
     case 2: return launch_mode<2>(a, mode, n_items, n_mrows, stream);
+#endif
+#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 3
     case 3: return launch_mode<3>(a, mode, n_items, n_mrows, stream);
+#endif
+#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 4
     case 4: return launch_mode<4>(a, mode, n_items, n_mrows, stream);
+#endif
+#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 5
     case 5: return launch_mode<5>(a, mode, n_items, n_mrows, stream);
+#endif
+#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 6
     case 6: return launch_mode<6>(a, mode, n_items, n_mrows, stream);
+#endif
+#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 7
     case 7: return launch_mode<7>(a, mode, n_items, n_mrows, stream);
+#endif
+#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 8
     case 8: return launch_mode<8>(a, mode, n_items, n_mrows, stream);
+#endif
+#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 9
     case 9: return launch_mode<9>(a, mode, n_items, n_mrows, stream);
+#endif
+#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 10
     case 10: return launch_mode<10>(a, mode, n_items, n_mrows, stream);
+#endif
+#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 11
     case 11: return launch_mode<11>(a, mode, n_items, n_mrows, stream);
+#endif
+#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 12
     case 12: return launch_mode<12>(a, mode, n_items, n_mrows, stream);
+#endif
+#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 13
     case 13: return launch_mode<13>(a, mode, n_items, n_mrows, stream);
+#endif
     default: return hipErrorInvalidValue;
   }
 }
@@ -1047,7 +1342,8 @@ hipError_t launch_half_iteration(const KernelArgs& a, int mode, long n_items, lo
 template <int NB, int MODE>
 static hipError_t launch_solve_nb(const float* A, const float* b, float* x, long batch, int f, int cg_iters,
                                   hipStream_t stream) {
-  const size_t floats = solve_lds_floats(f, NB == 0 ? kModeLUExact : MODE);
+  const size_t floats = NB == 0 ? solve_lds_floats(f, kModeLUExact)
+                                : (MODE == kModeLU ? lu_lds_floats(NB, f) : solve_lds_floats(f, MODE));
   const size_t lds = floats * sizeof(float);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   if (lds > 64 * 1024) {
@@ -1064,23 +1360,49 @@ template <int MODE>
 static hipError_t launch_solve_mode(const float* A, const float* b, float* x, long batch, int f, int cg_iters,
                                     hipStream_t stream) {
   switch (nb_for_f(f)) {
+#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 1
     case 1: return launch_solve_nb<1, MODE>(A, b, x, batch, f, cg_iters, stream);
+#endif
+#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 2
     case 2: return launch_solve_nb<2, MODE>(A, b, x, batch, f, cg_iters, stream);
+#endif
+#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 3
     case 3: return launch_solve_nb<3, MODE>(A, b, x, batch, f, cg_iters, stream);
+#endif
+#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 4
     case 4: return launch_solve_nb<4, MODE>(A, b, x, batch, f, cg_iters, stream);
+#endif
+#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 5
     case 5: return launch_solve_nb<5, MODE>(A, b, x, batch, f, cg_iters, stream);
+#endif
+#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 6
     case 6: return launch_solve_nb<6, MODE>(A, b, x, batch, f, cg_iters, stream);
+#endif
+#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 7
     case 7: return launch_solve_nb<7, MODE>(A, b, x, batch, f, cg_iters, stream);
+#endif
+#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 8
     case 8: return launch_solve_nb<8, MODE>(A, b, x, batch, f, cg_iters, stream);
+#endif
+#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 9
     case 9: return launch_solve_nb<9, MODE>(A, b, x, batch, f, cg_iters, stream);
+#endif
     default: break;
   }
   if constexpr (MODE == kModeLU) {  // register-resident elimination also for 128 < f <= 200 (G alone fills the LDS)
     switch (nb_for_f(f)) {
+#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 10
       case 10: return launch_solve_nb<10, MODE>(A, b, x, batch, f, cg_iters, stream);
+#endif
+#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 11
       case 11: return launch_solve_nb<11, MODE>(A, b, x, batch, f, cg_iters, stream);
+#endif
+#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 12
       case 12: return launch_solve_nb<12, MODE>(A, b, x, batch, f, cg_iters, stream);
+#endif
+#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 13
       case 13: return launch_solve_nb<13, MODE>(A, b, x, batch, f, cg_iters, stream);
+#endif
       default: break;
     }
   }

@@ -11,7 +11,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libALS.so")
+# CUMF_ALS_LIB: load another build of the library (kernel experiments, tools/lu_variants.sh)
+LIB_PATH = os.environ.get("CUMF_ALS_LIB") or os.path.join(CSRC, "libALS.so")
 MAIN_PATH = os.path.join(CSRC, "main")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
