@@ -35,13 +35,29 @@ namespace cumf {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-#ifndef CUMF_LU_ABL
-#define CUMF_LU_ABL 0
+// The file is compiled once per NB (Makefile: -DCUMF_NB_SLICE=1..13, the kernels of that
+// feature-block count) plus once with -DCUMF_NB_SLICE=0 (dispatch, NB-independent kernels,
+// shared state), so that the build runs in parallel; without the macro everything lands in
+// one translation unit.
+#ifndef CUMF_ONLY_NB
+#define CUMF_ONLY_NB 0  // experiments (tools/lu_variants.sh): build the kernels of one NB only
 #endif
-#ifndef CUMF_LU_PANEL
-#define CUMF_LU_PANEL 1
+#if !defined(CUMF_NB_SLICE)
+#define CUMF_SLICE_COMMON 1
+#define CUMF_SLICE_HAS(n) (CUMF_ONLY_NB == 0 || CUMF_ONLY_NB == (n))
+#elif CUMF_NB_SLICE == 0
+#define CUMF_SLICE_COMMON 1
+#define CUMF_SLICE_HAS(n) 0
+#else
+#define CUMF_SLICE_COMMON 0
+#define CUMF_SLICE_HAS(n) (CUMF_NB_SLICE == (n))
 #endif
-constexpr int kLuPanel = CUMF_LU_PANEL;  // pivots per barrier in the register-resident LU
+
+
+#ifndef CUMF_VARIANT_A
+#define CUMF_VARIANT_A 0  // ablation switches of tools/lu_variants.sh (timing experiments; results are wrong)
+#endif
+
 
 // ----------------------------------------------------------------------------------
 // Geometry of one workgroup (256 threads = 4 waves) for NB 16-wide feature blocks.
@@ -655,27 +671,25 @@ __device__ __forceinline__ void back_substitute_fast(const float* __restrict__ U
   });
 }
 
-// Register-resident symmetric elimination (the fast LU path, f <= 200), M pivots per barrier.
+// Register-resident symmetric elimination (the fast LU path, f <= 200).
 // The upper triangle of [A | b] is spread over the 16 x 16 thread grid, element (i, j) in
 // thread (i & 15, j & 15), register block (i >> 4, j >> 4); `load(bi, bj)` fetches this
 // thread's element of block (bi, bj) (from the accumulator tiles parked in LDS, or from
-// global memory).  Pivots are processed in panels of M consecutive rows:
-//   1. the thread rows owning the M panel rows publish them (as they stand, i.e. updated by
-//      all earlier panels) to the packed row store U (lu_row_off); ONE barrier;
-//   2. every thread reads the panel at its own row / column positions plus the M x M pivot
-//      block and eliminates the panel IN REGISTERS, redundantly (row r loses its
-//      projections on rows 0..r-1 of the panel): no further communication;
-//   3. rank-M update of the thread's registers  a_ij -= sum_r (u_ri / u_rr) * u_rj  (i > row r);
-//   4. the final values of panel rows 1..M-1 are written back to U by wave 0 after the NEXT
-//      barrier (by then nobody reads the published, un-eliminated copies any more).
+// global memory).  Per pivot k:
+//   1. the thread row owning row k publishes it (as it stands, i.e. updated by all earlier
+//      pivots) to the packed row store U (lu_row_off); the thread holding u_kk computes
+//      1 / u_kk meanwhile and publishes that too, so the reciprocal is off the readers'
+//      critical path; ONE barrier;
+//   2. every thread reads row k at its own row / column positions and applies
+//      a_ij -= (u_ki / u_kk) * u_kj  to its registers (i > k).
 // This is Gaussian elimination without pivoting restricted to the upper triangle (U = D L^T of
-// A = L U).  Measured (tools/lu_variants.sh): M = 2 halves the barriers and is not faster, the
-// step is bound by LDS reads + VALU, so M = 1 is the default.
+// A = L U).  Tried and measured slower or equal (tools/lu_variants.sh): panels of 2 or 4
+// pivots per barrier with a redundant in-register panel elimination (half / quarter the
+// barriers, same LDS reads: equal at M = 2, spills at M = 4), a rolled pivot loop (+5 %).
 // U may alias the memory `load` reads from: all loads complete before the first publish.
-template <int NB, int M, typename Load>
+template <int NB, typename Load>
 __device__ __forceinline__ void lu_solve_reg(Load load, float* __restrict__ U, int f, float* __restrict__ rdiag,
                                              float* __restrict__ x_global, int tid) {
-  static_assert(M == 1 || M == 2 || M == 4, "panel height");
   const int ti = tid >> 4, tj = tid & 15;
   float a[NB][NB];
   static_for<NB>([&](auto bic) {
@@ -687,43 +701,22 @@ __device__ __forceinline__ void lu_solve_reg(Load load, float* __restrict__ U, i
   });
   __syncthreads();
   // Rows >= f and columns > f of the register image are padding: never published, never read
-  // back, so updates run on them unmasked (whatever lands there is dead).  Panel reads of
-  // padding positions stay inside the row store and only feed dead registers.
+  // back, so updates run on them unmasked (whatever lands there is dead).  Reads of padding
+  // positions stay inside the row store and only feed dead registers.
   const bool last_col_ok = 16 * (NB - 1) + tj <= f;
-  float fin[M > 1 ? M - 1 : 1][NB];  // final panel rows 1..M-1 of the previous panel at this thread's columns
-  int fin_k0 = -1;
-  auto write_fin = [&]() {  // wave 0, thread rows 1..M-1: row fin_k0 + ti
-    if (M > 1 && fin_k0 >= 0 && tid < 64 && ti >= 1 && ti < M && fin_k0 + ti < f) {
-      float* w = U + lu_row_off<NB>(fin_k0 + ti) + tj;
-      const int kbp = fin_k0 >> 4;
-      static_for<NB>([&](auto bc) {
-        constexpr int b = decltype(bc)::value;
-        float v = fin[0][b];
-        static_for<(M > 1 ? M - 1 : 1)>([&](auto rc) {
-          constexpr int r = decltype(rc)::value;
-          v = (ti == r + 1) ? fin[r][b] : v;
-        });
-        if constexpr (b < NB - 1) {
-          if (b >= kbp) w[16 * b] = v;
-        }
-        if constexpr (b == NB - 1) {
-          if (last_col_ok) w[16 * b] = v;
-        }
-      });
-    }
-  };
-
   static_for<NB>([&](auto kbc) {
     constexpr int kb = decltype(kbc)::value;
     constexpr int pitch = lu_row_pitch<NB>(kb);
     float* blk = U + lu_block_off<NB>(kb) - 16 * kb;  // element (16 kb, 0) of this block row
-    for (int q = 0; q < 16 / M; ++q) {
-      const int kk0 = q * M;
-      const int k0 = 16 * kb + kk0;
-      if (k0 >= f) break;
-      // 1. publish: thread rows kk0 .. kk0+M-1 own the panel rows
-      if (ti >= kk0 && ti < kk0 + M && 16 * kb + ti < f) {
-        float* w = blk + ti * pitch + tj;
+    for (int kk = 0; kk < 16; ++kk) {
+      const int k = 16 * kb + kk;
+      if (k >= f) break;
+#if CUMF_VARIANT_A & 32
+      if (k >= 0) break;
+#endif
+      float* urow = blk + kk * pitch;
+      if (ti == kk) {
+        float* w = urow + tj;
         static_for<NB>([&](auto bjc) {
           constexpr int bj = decltype(bjc)::value;
           if constexpr (bj >= kb && bj < NB - 1) w[16 * bj] = a[kb][bj];
@@ -731,115 +724,50 @@ __device__ __forceinline__ void lu_solve_reg(Load load, float* __restrict__ U, i
             if (last_col_ok) w[16 * bj] = a[kb][bj];
           }
         });
+        if (tj == kk) {
+          const float piv = a[kb][kb];
+          const float t = __builtin_amdgcn_rcpf(piv);
+          rdiag[k] = fmaf(fmaf(-piv, t, 1.0f), t, t);  // one Newton step: 1/pivot to ~1 ulp
+        }
       }
+#if !(CUMF_VARIANT_A & 4)
       __syncthreads();
-      write_fin();  // previous panel's final rows (no one reads their published copies any more)
-      // 2. read the panel; all reads unconditional and issued together
-      float ui[M][NB], uj[M][NB], P[M][M];
-      static_for<M>([&](auto rc) {
-        constexpr int r = decltype(rc)::value;
-        // a short last panel (f odd multiple of M) re-reads its first row; masked below
-        const float* urow = blk + ((k0 + r < f) ? kk0 + r : kk0) * pitch;
-        static_for<NB>([&](auto bc) {
-          constexpr int b = decltype(bc)::value;
-          if constexpr (b >= kb) {
-            ui[r][b] = urow[16 * b + ti];
-            uj[r][b] = urow[16 * b + tj];
-          }
-        });
-        static_for<M>([&](auto cc) {
-          constexpr int c = decltype(cc)::value;
-          if constexpr (c >= r) P[r][c] = urow[k0 + c];
-        });
-      });
-      bool valid[M];
-      static_for<M>([&](auto rc) {
-        constexpr int r = decltype(rc)::value;
-        valid[r] = k0 + r < f;
-        if constexpr (r > 0) {
-          static_for<NB>([&](auto bc) {
-            constexpr int b = decltype(bc)::value;
-            if constexpr (b >= kb) {
-              ui[r][b] = valid[r] ? ui[r][b] : 0.f;
-              uj[r][b] = valid[r] ? uj[r][b] : 0.f;
-            }
-          });
-          static_for<M>([&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            if constexpr (c >= r) P[r][c] = valid[r] ? P[r][c] : (c == r ? 1.f : 0.f);
-          });
+#endif
+      float ui[NB], uj[NB];
+      const float nrp = -rdiag[k];
+      static_for<NB>([&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        if constexpr (b >= kb) {
+          uj[b] = urow[16 * b + tj];
+#if CUMF_VARIANT_A & 1
+          ui[b] = uj[b];
+#else
+          ui[b] = urow[16 * b + ti];
+#endif
         }
       });
-      // in-register elimination of the panel
-      float rp[M];
-      static_for<M>([&](auto rc) {
-        constexpr int r = decltype(rc)::value;
-        static_for<M>([&](auto qc) {
-          constexpr int q2 = decltype(qc)::value;
-          if constexpr (q2 < r) {
-            const float m = -P[q2][r] * rp[q2];  // -(multiplier of row r w.r.t. pivot q2)
-            static_for<M>([&](auto cc) {
-              constexpr int c = decltype(cc)::value;
-              if constexpr (c >= r) P[r][c] = fmaf(m, P[q2][c], P[r][c]);
-            });
-            static_for<NB>([&](auto bc) {
-              constexpr int b = decltype(bc)::value;
-              if constexpr (b >= kb) {
-                ui[r][b] = fmaf(m, ui[q2][b], ui[r][b]);
-                uj[r][b] = fmaf(m, uj[q2][b], uj[r][b]);
-              }
-            });
-          }
-        });
-        float t = __builtin_amdgcn_rcpf(P[r][r]);
-        rp[r] = fmaf(fmaf(-P[r][r], t, 1.0f), t, t);  // one Newton step: 1/pivot to ~1 ulp
-      });
-      if (tid == 0) {
-        static_for<M>([&](auto rc) {
-          constexpr int r = decltype(rc)::value;
-          if (valid[r]) rdiag[k0 + r] = rp[r];
-        });
-      }
-      // 3. multipliers (in place of ui) and the rank-M update
-      static_for<M>([&](auto rc) {
-        constexpr int r = decltype(rc)::value;
-        static_for<NB>([&](auto bc) {
-          constexpr int b = decltype(bc)::value;
-          if constexpr (b > kb) ui[r][b] = valid[r] ? -ui[r][b] * rp[r] : 0.f;
-          if constexpr (b == kb) ui[r][b] = (valid[r] && ti > kk0 + r) ? -ui[r][b] * rp[r] : 0.f;
-        });
+      static_for<NB>([&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        if constexpr (b > kb) ui[b] = ui[b] * nrp;
+        if constexpr (b == kb) ui[b] = (ti > kk) ? ui[b] * nrp : 0.f;
       });
       static_for<NB>([&](auto bic) {
         constexpr int bi = decltype(bic)::value;
         static_for<NB>([&](auto bjc) {
           constexpr int bj = decltype(bjc)::value;
-          if constexpr (bi >= kb && bj >= bi) {
-            static_for<M>([&](auto rc) {
-              constexpr int r = decltype(rc)::value;
-              a[bi][bj] = fmaf(ui[r][bi], uj[r][bj], a[bi][bj]);
-            });
-          }
+#if CUMF_VARIANT_A & 2
+          if constexpr (bi >= kb && bj == bi) a[bi][bj] = fmaf(ui[bi], uj[bj], a[bi][bj]);
+#else
+          if constexpr (bi >= kb && bj >= bi) a[bi][bj] = fmaf(ui[bi], uj[bj], a[bi][bj]);
+#endif
         });
       });
-      // 4. remember the final panel rows 1..M-1
-      if constexpr (M > 1) {
-        static_for<M - 1>([&](auto rc) {
-          constexpr int r = decltype(rc)::value;
-          static_for<NB>([&](auto bc) {
-            constexpr int b = decltype(bc)::value;
-            if constexpr (b >= kb) fin[r][b] = uj[r + 1][b];
-          });
-        });
-        fin_k0 = k0;
-      }
     }
   });
   __syncthreads();
-  if constexpr (M > 1) {
-    write_fin();
-    __syncthreads();
-  }
+#if !(CUMF_VARIANT_A & 8)
   if (tid < 64) back_substitute_fast<NB, (16 * NB + 63) / 64>(U, f, rdiag, x_global, tid);
+#endif
 }
 
 // Loaders of lu_solve_reg.  TileLoad: the accumulator tiles parked in LDS by tiles_to_tiled.
@@ -903,7 +831,7 @@ __device__ __forceinline__ void solve_row(float* smem, const KernelArgs& a, int 
     if constexpr (MODE == kModeCG)
       cg_solve_lds<NB>(G, ldg, f, smem + solve_g_floats(f, MODE), x, a.cg_iters, tid);
     else
-      lu_solve_reg<NB, kLuPanel>(TileLoad<NB>{smem, f}, smem, f, smem + lu_packed_floats(NB), x, tid);
+      lu_solve_reg<NB>(TileLoad<NB>{smem, f}, smem, f, smem + lu_packed_floats(NB), x, tid);
   }
 }
 
@@ -1084,7 +1012,7 @@ __global__ __launch_bounds__(kThreads) void solve_lds_kernel(const float* __rest
   const size_t sys = blockIdx.x;
   const float* As = A + sys * (size_t)f * f;
   if constexpr (NB != 0 && MODE == kModeLU) {
-    lu_solve_reg<NB, kLuPanel>(GlobalLoad<NB>{As, b + sys * f, f}, smem, f, smem + lu_packed_floats(NB), x + sys * f,
+    lu_solve_reg<NB>(GlobalLoad<NB>{As, b + sys * f, f}, smem, f, smem + lu_packed_floats(NB), x + sys * f,
                                tid);
     return;
   }
@@ -1102,6 +1030,7 @@ __global__ __launch_bounds__(kThreads) void solve_lds_kernel(const float* __rest
     cg_solve_lds<NB>(G, ldg, f, smem + solve_g_floats(f, MODE), x + sys * f, cg_iters, tid);
 }
 
+#if CUMF_SLICE_COMMON
 // CG with A streamed from global memory every mat-vec, for f too large for an
 // LDS-resident system (f > 128).  One workgroup per system, thread t owns row t
 // (blockDim = f rounded up to 64; same shape as cg.cu:36-231, wave64 reductions).
@@ -1220,10 +1149,19 @@ __global__ __launch_bounds__(kThreads) void sse_kernel(const float* __restrict__
 
 // Optional per-kernel HIP-event timing of the last half-iteration (bench.py's roofline
 // leg): events are recorded on the SAME stream the kernels are launched on.
-static bool g_timing = false;
-static hipEvent_t g_ev[3] = {nullptr, nullptr, nullptr};
-static bool g_timed_item = false, g_timed_reduce = false;
+#endif  // CUMF_SLICE_COMMON
 
+#if CUMF_SLICE_COMMON
+bool g_timing = false;
+hipEvent_t g_ev[3] = {nullptr, nullptr, nullptr};
+bool g_timed_item = false, g_timed_reduce = false;
+#else
+extern bool g_timing;
+extern hipEvent_t g_ev[3];
+extern bool g_timed_item, g_timed_reduce;
+#endif
+
+#if CUMF_SLICE_COMMON
 void set_kernel_timing(bool on) {
   g_timing = on;
   if (on && g_ev[0] == nullptr)
@@ -1239,6 +1177,8 @@ hipError_t last_kernel_ms(float* item_ms, float* reduce_ms) {
   if (g_timed_reduce) (void)hipEventElapsedTime(reduce_ms, g_ev[1], g_ev[2]);
   return hipSuccess;
 }
+#endif  // CUMF_SLICE_COMMON
+
 template <int NB, typename VT, int MODE>
 static hipError_t launch_nb(const KernelArgs& a, long n_items, long n_mrows, hipStream_t stream) {
   const size_t stage_floats = (2 * (size_t)kStage + 8) * Geo<NB>::LD;  // + read-ahead pad of mma_stage
@@ -1293,52 +1233,6 @@ static hipError_t launch_mode(const KernelArgs& a, int mode, long n_items, long 
   return hipErrorInvalidValue;
 }
 
-hipError_t launch_half_iteration(const KernelArgs& a, int mode, long n_items, long n_mrows, hipStream_t stream) {
-  const int nb = nb_for_f(a.f);
-  switch (nb) {
-#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 1
-    case 1: return launch_mode<1>(a, mode, n_items, n_mrows, stream);
-#endif
-#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 2
-    case 2: return launch_mode<2>(a, mode, n_items, n_mrows, stream);
-#endif
-#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 3
-    case 3: return launch_mode<3>(a, mode, n_items, n_mrows, stream);
-#endif
-#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 4
-    case 4: return launch_mode<4>(a, mode, n_items, n_mrows, stream);
-#endif
-#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 5
-    case 5: return launch_mode<5>(a, mode, n_items, n_mrows, stream);
-#endif
-#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 6
-    case 6: return launch_mode<6>(a, mode, n_items, n_mrows, stream);
-#endif
-#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 7
-    case 7: return launch_mode<7>(a, mode, n_items, n_mrows, stream);
-#endif
-#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 8
-    case 8: return launch_mode<8>(a, mode, n_items, n_mrows, stream);
-#endif
-#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 9
-    case 9: return launch_mode<9>(a, mode, n_items, n_mrows, stream);
-#endif
-#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 10
-    case 10: return launch_mode<10>(a, mode, n_items, n_mrows, stream);
-#endif
-#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 11
-    case 11: return launch_mode<11>(a, mode, n_items, n_mrows, stream);
-#endif
-#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 12
-    case 12: return launch_mode<12>(a, mode, n_items, n_mrows, stream);
-#endif
-#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 13
-    case 13: return launch_mode<13>(a, mode, n_items, n_mrows, stream);
-#endif
-    default: return hipErrorInvalidValue;
-  }
-}
-
 template <int NB, int MODE>
 static hipError_t launch_solve_nb(const float* A, const float* b, float* x, long batch, int f, int cg_iters,
                                   hipStream_t stream) {
@@ -1356,75 +1250,144 @@ static hipError_t launch_solve_nb(const float* A, const float* b, float* x, long
   return hipGetLastError();
 }
 
-template <int MODE>
-static hipError_t launch_solve_mode(const float* A, const float* b, float* x, long batch, int f, int cg_iters,
-                                    hipStream_t stream) {
-  switch (nb_for_f(f)) {
-#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 1
-    case 1: return launch_solve_nb<1, MODE>(A, b, x, batch, f, cg_iters, stream);
-#endif
-#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 2
-    case 2: return launch_solve_nb<2, MODE>(A, b, x, batch, f, cg_iters, stream);
-#endif
-#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 3
-    case 3: return launch_solve_nb<3, MODE>(A, b, x, batch, f, cg_iters, stream);
-#endif
-#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 4
-    case 4: return launch_solve_nb<4, MODE>(A, b, x, batch, f, cg_iters, stream);
-#endif
-#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 5
-    case 5: return launch_solve_nb<5, MODE>(A, b, x, batch, f, cg_iters, stream);
-#endif
-#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 6
-    case 6: return launch_solve_nb<6, MODE>(A, b, x, batch, f, cg_iters, stream);
-#endif
-#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 7
-    case 7: return launch_solve_nb<7, MODE>(A, b, x, batch, f, cg_iters, stream);
-#endif
-#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 8
-    case 8: return launch_solve_nb<8, MODE>(A, b, x, batch, f, cg_iters, stream);
-#endif
-#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 9
-    case 9: return launch_solve_nb<9, MODE>(A, b, x, batch, f, cg_iters, stream);
-#endif
-    default: break;
+// Per-NB entry points (one translation unit each, see CUMF_NB_SLICE above).
+template <int NB>
+hipError_t slice_half_iteration(const KernelArgs& a, int mode, long n_items, long n_mrows, hipStream_t stream);
+template <int NB>
+hipError_t slice_solve(const float* A, const float* b, float* x, long batch, int f, int mode, int cg_iters,
+                       hipStream_t stream);
+
+#define CUMF_DECLARE_SLICE(N)                                                                                   \
+  template <>                                                                                                    \
+  hipError_t slice_half_iteration<N>(const KernelArgs& a, int mode, long n_items, long n_mrows, hipStream_t stream); \
+  template <>                                                                                                    \
+  hipError_t slice_solve<N>(const float* A, const float* b, float* x, long batch, int f, int mode, int cg_iters, \
+                            hipStream_t stream);
+#define CUMF_STUB_SLICE(N)                                                                                       \
+  template <>                                                                                                    \
+  hipError_t slice_half_iteration<N>(const KernelArgs&, int, long, long, hipStream_t) {                          \
+    return hipErrorInvalidValue;                                                                                 \
+  }                                                                                                              \
+  template <>                                                                                                    \
+  hipError_t slice_solve<N>(const float*, const float*, float*, long, int, int, int, hipStream_t) {              \
+    return hipErrorInvalidValue;                                                                                 \
   }
-  if constexpr (MODE == kModeLU) {  // register-resident elimination also for 128 < f <= 200 (G alone fills the LDS)
-    switch (nb_for_f(f)) {
-#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 10
-      case 10: return launch_solve_nb<10, MODE>(A, b, x, batch, f, cg_iters, stream);
-#endif
-#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 11
-      case 11: return launch_solve_nb<11, MODE>(A, b, x, batch, f, cg_iters, stream);
-#endif
-#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 12
-      case 12: return launch_solve_nb<12, MODE>(A, b, x, batch, f, cg_iters, stream);
-#endif
-#if !defined(CUMF_ONLY_NB) || CUMF_ONLY_NB == 13
-      case 13: return launch_solve_nb<13, MODE>(A, b, x, batch, f, cg_iters, stream);
-#endif
-      default: break;
-    }
+#define CUMF_DEFINE_SLICE(N)                                                                                     \
+  template <>                                                                                                    \
+  hipError_t slice_half_iteration<N>(const KernelArgs& a, int mode, long n_items, long n_mrows,                 \
+                                     hipStream_t stream) {                                                       \
+    return launch_mode<N>(a, mode, n_items, n_mrows, stream);                                                    \
+  }                                                                                                              \
+  template <>                                                                                                    \
+  hipError_t slice_solve<N>(const float* A, const float* b, float* x, long batch, int f, int mode, int cg_iters, \
+                            hipStream_t stream) {                                                                \
+    if (mode == kModeCG) {                                                                                       \
+      if constexpr (N <= kMaxFusedNB) return launch_solve_nb<N, kModeCG>(A, b, x, batch, f, cg_iters, stream);   \
+      return hipErrorInvalidValue;                                                                               \
+    }                                                                                                            \
+    return launch_solve_nb<N, kModeLU>(A, b, x, batch, f, cg_iters, stream);                                     \
   }
-  return hipErrorInvalidValue;
+
+CUMF_DECLARE_SLICE(1) CUMF_DECLARE_SLICE(2) CUMF_DECLARE_SLICE(3) CUMF_DECLARE_SLICE(4) CUMF_DECLARE_SLICE(5)
+CUMF_DECLARE_SLICE(6) CUMF_DECLARE_SLICE(7) CUMF_DECLARE_SLICE(8) CUMF_DECLARE_SLICE(9) CUMF_DECLARE_SLICE(10)
+CUMF_DECLARE_SLICE(11) CUMF_DECLARE_SLICE(12) CUMF_DECLARE_SLICE(13)
+#if CUMF_SLICE_HAS(1)
+CUMF_DEFINE_SLICE(1)
+#elif CUMF_ONLY_NB != 0
+CUMF_STUB_SLICE(1)
+#endif
+#if CUMF_SLICE_HAS(2)
+CUMF_DEFINE_SLICE(2)
+#elif CUMF_ONLY_NB != 0
+CUMF_STUB_SLICE(2)
+#endif
+#if CUMF_SLICE_HAS(3)
+CUMF_DEFINE_SLICE(3)
+#elif CUMF_ONLY_NB != 0
+CUMF_STUB_SLICE(3)
+#endif
+#if CUMF_SLICE_HAS(4)
+CUMF_DEFINE_SLICE(4)
+#elif CUMF_ONLY_NB != 0
+CUMF_STUB_SLICE(4)
+#endif
+#if CUMF_SLICE_HAS(5)
+CUMF_DEFINE_SLICE(5)
+#elif CUMF_ONLY_NB != 0
+CUMF_STUB_SLICE(5)
+#endif
+#if CUMF_SLICE_HAS(6)
+CUMF_DEFINE_SLICE(6)
+#elif CUMF_ONLY_NB != 0
+CUMF_STUB_SLICE(6)
+#endif
+#if CUMF_SLICE_HAS(7)
+CUMF_DEFINE_SLICE(7)
+#elif CUMF_ONLY_NB != 0
+CUMF_STUB_SLICE(7)
+#endif
+#if CUMF_SLICE_HAS(8)
+CUMF_DEFINE_SLICE(8)
+#elif CUMF_ONLY_NB != 0
+CUMF_STUB_SLICE(8)
+#endif
+#if CUMF_SLICE_HAS(9)
+CUMF_DEFINE_SLICE(9)
+#elif CUMF_ONLY_NB != 0
+CUMF_STUB_SLICE(9)
+#endif
+#if CUMF_SLICE_HAS(10)
+CUMF_DEFINE_SLICE(10)
+#elif CUMF_ONLY_NB != 0
+CUMF_STUB_SLICE(10)
+#endif
+#if CUMF_SLICE_HAS(11)
+CUMF_DEFINE_SLICE(11)
+#elif CUMF_ONLY_NB != 0
+CUMF_STUB_SLICE(11)
+#endif
+#if CUMF_SLICE_HAS(12)
+CUMF_DEFINE_SLICE(12)
+#elif CUMF_ONLY_NB != 0
+CUMF_STUB_SLICE(12)
+#endif
+#if CUMF_SLICE_HAS(13)
+CUMF_DEFINE_SLICE(13)
+#elif CUMF_ONLY_NB != 0
+CUMF_STUB_SLICE(13)
+#endif
+
+#if CUMF_SLICE_COMMON
+#define CUMF_NB_CASE(N, call) case N: return call;
+
+hipError_t launch_half_iteration(const KernelArgs& a, int mode, long n_items, long n_mrows, hipStream_t stream) {
+#define CUMF_HALF(N) CUMF_NB_CASE(N, slice_half_iteration<N>(a, mode, n_items, n_mrows, stream))
+  switch (nb_for_f(a.f)) {
+    CUMF_HALF(1) CUMF_HALF(2) CUMF_HALF(3) CUMF_HALF(4) CUMF_HALF(5) CUMF_HALF(6) CUMF_HALF(7)
+    CUMF_HALF(8) CUMF_HALF(9) CUMF_HALF(10) CUMF_HALF(11) CUMF_HALF(12) CUMF_HALF(13)
+    default: return hipErrorInvalidValue;
+  }
+#undef CUMF_HALF
 }
 
 hipError_t launch_solve_batched(const float* A, const float* b, float* x, long batch, int f, int mode, int cg_iters,
                                 hipStream_t stream) {
   if (batch <= 0) return hipSuccess;
-  if (f > 128) {
-    if (mode == kModeCG) {
-      const int threads = ((f + 63) / 64) * 64;
-      const size_t lds = (threads + 16) * sizeof(float);
-      hipLaunchKernelGGL(cg_global_kernel, dim3((unsigned)batch), dim3(threads), lds, stream, A, x, b, f, cg_iters);
-      return hipGetLastError();
-    }
-    if (mode == kModeLUExact) return launch_solve_nb<0, kModeLU>(A, b, x, batch, f, 0, stream);
-    return launch_solve_mode<kModeLU>(A, b, x, batch, f, cg_iters, stream);
-  }
-  if (mode == kModeCG) return launch_solve_mode<kModeCG>(A, b, x, batch, f, cg_iters, stream);
   if (mode == kModeLUExact) return launch_solve_nb<0, kModeLU>(A, b, x, batch, f, 0, stream);
-  return launch_solve_mode<kModeLU>(A, b, x, batch, f, cg_iters, stream);
+  if (f > 128 && mode == kModeCG) {  // system too large for the LDS: A streamed from global memory
+    const int threads = ((f + 63) / 64) * 64;
+    const size_t lds = (threads + 16) * sizeof(float);
+    hipLaunchKernelGGL(cg_global_kernel, dim3((unsigned)batch), dim3(threads), lds, stream, A, x, b, f, cg_iters);
+    return hipGetLastError();
+  }
+  // LDS-resident CG (f <= 128) or register-resident LU (f <= 200)
+#define CUMF_SOLVE(N) CUMF_NB_CASE(N, slice_solve<N>(A, b, x, batch, f, mode, cg_iters, stream))
+  switch (nb_for_f(f)) {
+    CUMF_SOLVE(1) CUMF_SOLVE(2) CUMF_SOLVE(3) CUMF_SOLVE(4) CUMF_SOLVE(5) CUMF_SOLVE(6) CUMF_SOLVE(7)
+    CUMF_SOLVE(8) CUMF_SOLVE(9) CUMF_SOLVE(10) CUMF_SOLVE(11) CUMF_SOLVE(12) CUMF_SOLVE(13)
+    default: return hipErrorInvalidValue;
+  }
+#undef CUMF_SOLVE
 }
 
 hipError_t launch_sse(const float* val, const int* row, const int* col, const float* thetaT, const float* XT,
@@ -1438,5 +1401,7 @@ hipError_t launch_sse(const float* val, const int* row, const int* col, const fl
                      (long long)count, f, surpass_nan, out);
   return hipGetLastError();
 }
+
+#endif  // CUMF_SLICE_COMMON
 
 }  // namespace cumf

@@ -35,7 +35,7 @@ def build(force: bool = False) -> str:
     """Compile libALS.so and ./main for gfx950 with hipcc (cross-compiles without a GPU)."""
     if force:
         subprocess.run(["make", "-s", "-C", CSRC, "clean"], check=True)
-    subprocess.run(["make", "-s", "-C", CSRC, "build"], check=True)
+    subprocess.run(["make", "-s", f"-j{os.cpu_count() or 4}", "-C", CSRC, "build"], check=True)
     return LIB_PATH
 
 
