@@ -118,7 +118,9 @@ extern "C" int cumf_plan_create(cumf_plan_t** out, const void* rowptr_host, int 
   // index order, so the short items fill the tail.
   std::vector<long> order(item_row.size());
   std::iota(order.begin(), order.end(), 0L);
-  std::stable_sort(order.begin(), order.end(), [&](long a, long b) { return item_len[a] > item_len[b]; });
+  static const int order_mode = getenv("CUMF_ALS_ORDER") ? atoi(getenv("CUMF_ALS_ORDER")) : 0;
+  if (order_mode == 0)
+    std::stable_sort(order.begin(), order.end(), [&](long a, long b) { return item_len[a] > item_len[b]; });
   auto permute = [&](auto& v) {
     auto copy = v;
     for (size_t i = 0; i < order.size(); ++i) v[i] = copy[order[i]];
