@@ -88,7 +88,7 @@ extern "C" float cumf_doALS_ex(const int* csrRowIndexHostPtr, const int* csrColI
   if (!quiet) printf("*******parameters: m: %d, n:  %d, f: %d, nnz: %ld \n", m, n, f, nnz);
   if (X_BATCH < 1) X_BATCH = 1;
   if (THETA_BATCH < 1) THETA_BATCH = 1;
-  if (cumf::nb_for_f(f) > cumf::kMaxFusedNB) fused = 0;  // LDS-resident solve needs f <= 128
+  if (!cumf::fused_supported(f, solver == CUMF_SOLVER_LU ? cumf::kModeLU : cumf::kModeCG)) fused = 0;  // CG: f <= 128
 
   if (!quiet) printf("*******start allocating memory on GPU...\n");
   int* csrColIndex = to_device(csrColIndexHostPtr, (size_t)nnz);

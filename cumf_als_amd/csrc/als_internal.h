@@ -35,6 +35,11 @@ __host__ __device__ constexpr size_t solve_lds_floats(int f, int mode) {
   return solve_g_floats(f, mode) + (mode == kModeCG ? (size_t)kCgExtraFloats : 0);
 }
 
+// Which (f, solver) pairs the fused Gram+solve kernel covers.
+__host__ __device__ constexpr bool fused_supported(int f, int mode) {
+  return mode == kModeLU ? nb_for_f(f) <= nb_for_f(kMaxF) : nb_for_f(f) <= kMaxFusedNB;
+}
+
 struct KernelArgs {
   // plan items (one workgroup each)
   const int* item_row;

@@ -1227,9 +1227,11 @@ static hipError_t launch_mode(const KernelArgs& a, int mode, long n_items, long 
     if (mode == kModeCG)
       return v4 ? launch_nb<NB, f32x4, kModeCG>(a, n_items, n_mrows, stream)
                 : launch_nb<NB, f32x2, kModeCG>(a, n_items, n_mrows, stream);
+  }
+  // the register LU keeps only the packed upper triangle in LDS: fused up to f = 200
+  if (mode == kModeLU)
     return v4 ? launch_nb<NB, f32x4, kModeLU>(a, n_items, n_mrows, stream)
               : launch_nb<NB, f32x2, kModeLU>(a, n_items, n_mrows, stream);
-  }
   return hipErrorInvalidValue;
 }
 

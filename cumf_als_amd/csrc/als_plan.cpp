@@ -211,9 +211,10 @@ extern "C" int cumf_als_update_fused(const cumf_plan_t* p, const int* colidx, co
     fprintf(stderr, "cumf_als_update_fused: plan/f mismatch\n");
     return (int)hipErrorInvalidValue;
   }
-  if (nb_for_f(f) > kMaxFusedNB) {
-    fprintf(stderr, "cumf_als_update_fused: f = %d > 128 needs the materialising path "
-                    "(cumf_get_hermitian + cumf_*_solve_batched)\n", f);
+  if (!fused_supported(f, solver == CUMF_SOLVER_LU ? kModeLU : kModeCG)) {
+    fprintf(stderr, "cumf_als_update_fused: f = %d with this solver needs the materialising path "
+                    "(cumf_get_hermitian + cumf_*_solve_batched): the fused CG holds the full system "
+                    "in LDS (f <= 128), the fused LU its packed upper triangle (f <= 200)\n", f);
     return (int)hipErrorInvalidValue;
   }
   KernelArgs a = base_args(p, colidx, val, gather, f, lambda);

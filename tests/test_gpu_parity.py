@@ -116,8 +116,8 @@ def test_cg_solve(oracle, alslib, f):
     assert err <= 2e-4 * max(1.0, np.abs(x_o).max()), err
 
 
-@pytest.mark.parametrize("solver", ["cg", "lu"])
-@pytest.mark.parametrize("f", [10, 100])
+@pytest.mark.parametrize("solver,f", [("cg", 10), ("cg", 100), ("cg", 128), ("lu", 10), ("lu", 100), ("lu", 128),
+                                      ("lu", 200)])
 def test_fused_half_iteration(oracle, alslib, solver, f):
     _need_gpu()
     from cumf_als_amd import als
