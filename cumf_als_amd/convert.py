@@ -84,6 +84,12 @@ def convert_text(train_path: str, test_path: str, out_dir: str, order: str = "co
     return ratings
 
 
+TEST_SLAB_FILES = {
+    "test_data": ("R_test_coo.data.bin", np.float32),
+    "test_row": ("R_test_coo.row.bin", np.int32),   # slab-local row ids
+    "test_col": ("R_test_coo.col.bin", np.int32),
+}
+
 SLAB_FILES = {
     "csr_data": ("R_train_csr.data.bin", np.float32),
     "csr_indptr": ("R_train_csr.indptr.bin", np.int32),
@@ -108,7 +114,11 @@ def split_dataset(data_dir: str, out_dir: str, gpus: int, m: int, n: int, nnz: i
         cp, ri, cv = local_csc_of_slab(rp, ci, va, n)
         arrays = {"csr_data": va, "csr_indptr": rp, "csr_indices": ci,
                   "csc_data": cv, "csc_indices": ri, "csc_indptr": cp}
-        for key, (name, dtype) in SLAB_FILES.items():
+        # the test ratings whose row falls in the slab, row ids rebased (the reference keeps the
+        # test set as per-GPU CSC files, hugewiki.cu:2345-2354; COO is what the SSE kernel reads)
+        sel = np.nonzero((d["test_row"] >= r0) & (d["test_row"] < r1))[0]
+        arrays.update(test_data=d["test_data"][sel], test_row=d["test_row"][sel] - r0, test_col=d["test_col"][sel])
+        for key, (name, dtype) in {**SLAB_FILES, **TEST_SLAB_FILES}.items():
             np.ascontiguousarray(arrays[key], dtype=dtype).tofile(os.path.join(out_dir, f"{name}{g}"))
     with open(os.path.join(out_dir, "slabs.txt"), "w") as fh:
         fh.write(" ".join(str(int(b)) for b in bounds) + "\n")
@@ -118,7 +128,7 @@ def split_dataset(data_dir: str, out_dir: str, gpus: int, m: int, n: int, nnz: i
 def read_slab(out_dir: str, g: int, rows: int, n: int):
     """Load slab g written by `split_dataset` (rows = its row count) -> dict of numpy arrays."""
     out = {}
-    for key, (name, dtype) in SLAB_FILES.items():
+    for key, (name, dtype) in {**SLAB_FILES, **TEST_SLAB_FILES}.items():
         out[key] = np.fromfile(os.path.join(out_dir, f"{name}{g}"), dtype=dtype)
     if out["csr_indptr"].size != rows + 1 or out["csc_indptr"].size != n + 1:
         raise ValueError(f"slab {g}: row pointer sizes do not match rows={rows}, n={n}")

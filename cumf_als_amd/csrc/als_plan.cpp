@@ -275,6 +275,11 @@ extern "C" int cumf_last_kernel_ms(float* item_kernel_ms, float* reduce_kernel_m
   return 0;
 }
 
+extern "C" void cumf_rand_init(float* a, long count, float scale, long seed) {
+  if (seed >= 0) srand((unsigned)seed);
+  for (long k = 0; k < count; ++k) a[k] = scale * ((float)rand() / (float)RAND_MAX);
+}
+
 extern "C" int cumf_als_version(void) { return 100; }
 extern "C" const char* cumf_als_arch(void) { return "gfx950"; }
 

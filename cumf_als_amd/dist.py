@@ -115,6 +115,12 @@ class HipOps:
         else:
             self.als.lu_solve(tt, rhs, x)
 
+    def sse(self, val, row, col, thetaT, XT) -> float:
+        """sum (r - x_row . theta_col)^2 over the given ratings (als.cu:191-219)."""
+        if val.numel() == 0:
+            return 0.0
+        return float(self.als.sse(val, row, col, thetaT, XT).item())
+
 
 # ----------------------------------------------------------------------------------------
 # collectives: on device tensors with nccl (RCCL), staged through the host with gloo
@@ -324,6 +330,21 @@ class DistALS:
             gathered = torch.empty((w * k, f), dtype=torch.float32, device=dev)
             all_gather_equal(gathered, x, self.group)        # replaces hugewiki.cu:2744-2745
             self.thetaT[off: off + size].copy_(gathered[:size])
+
+    # -- RMSE (hugewiki.cu:2750-2862: per-GPU SSE over its slab, summed) -------------------------
+    def slab_sse(self, val: torch.Tensor, row_local: torch.Tensor, col: torch.Tensor) -> float:
+        """Sum over ALL ranks of the squared errors of each rank's ratings; `row_local` indexes the
+        rank's own X slab (row ids rebased to the slab), `col` is global."""
+        if self.scheme == "reduce":
+            mine = self.XT
+        else:
+            mine = self.XT[int(self.xb[self.rank]):int(self.xb[self.rank + 1])]
+        t = torch.tensor([self.ops.sse(val, row_local, col, self.thetaT, mine)], dtype=torch.float64)
+        if dist.is_initialized() and self.world > 1:
+            if dist.get_backend() == "nccl":
+                t = t.to(self.XT.device)
+            dist.all_reduce(t, group=self.group)
+        return float(t.item())
 
     def iterate(self, iters: int = 1) -> None:
         for _ in range(iters):

@@ -20,7 +20,7 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 C_SYMBOLS = [
     "cumf_doALS", "cumf_doALS_ex", "cumf_plan_create", "cumf_plan_destroy", "cumf_plan_info",
     "cumf_als_update_fused", "cumf_get_hermitian", "cumf_cg_solve_batched", "cumf_lu_solve_batched",
-    "cumf_sse", "cumf_set_kernel_timing", "cumf_last_kernel_ms", "cumf_als_version", "cumf_als_arch",
+    "cumf_sse", "cumf_set_kernel_timing", "cumf_last_kernel_ms", "cumf_rand_init", "cumf_als_version", "cumf_als_arch",
 ]
 # C++-linkage drop-in symbols (include/als.h, include/cg.h) under the reference's mangled names
 CXX_SYMBOLS = [
@@ -75,6 +75,8 @@ def load():
     lib.cumf_set_kernel_timing.argtypes = [C.c_int]
     lib.cumf_last_kernel_ms.restype = C.c_int
     lib.cumf_last_kernel_ms.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.cumf_rand_init.restype = None
+    lib.cumf_rand_init.argtypes = [fp, C.c_long, C.c_float, C.c_long]
     lib.cumf_als_version.restype = C.c_int
     lib.cumf_als_arch.restype = C.c_char_p
     host_args = [vp] * 12 + [C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_float, C.c_int, C.c_int, C.c_int,

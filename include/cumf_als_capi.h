@@ -126,6 +126,11 @@ int cumf_set_kernel_timing(int enable);
 int cumf_last_kernel_ms(float* item_kernel_ms, float* reduce_kernel_ms);
 
 /* Library/version probe used by the loaders' "fail loudly" checks. */
+/* Factor initialisation of the reference's hosts: a[k] = scale * ((float)rand() / (float)RAND_MAX)
+ * for k in order, libc rand() (main.cpp:72-76 with scale 0.2 after srand(0); als_tf.cc:121-123
+ * with scale 0.1, unseeded).  Host pointer.  seed < 0: continue the current rand() stream. */
+void cumf_rand_init(float* a, long count, float scale, long seed);
+
 int cumf_als_version(void);
 const char* cumf_als_arch(void);
 

@@ -50,6 +50,13 @@ class OracleOps:
         x.copy_(torch.from_numpy(np.ascontiguousarray(out, np.float32)))
 
 
+    def sse(self, val, row, col, thetaT, XT):
+        if val.numel() == 0:
+            return 0.0
+        return float(pyoracle.sse(val.numpy(), row.numpy(), col.numpy(), thetaT.numpy(), XT.numpy(),
+                                  val.numel(), thetaT.shape[-1]))
+
+
 def worker(rank, world, port, scheme, solver, d, m, n, f, lam, iters, theta_batch, theta0, q, ops_kind="oracle"):
     """Entry point of one rank (spawned): runs DistALS and returns full factors through `q`."""
     import os
@@ -75,5 +82,23 @@ def worker(rank, world, port, scheme, solver, d, m, n, f, lam, iters, theta_batc
         x = eng.full_XT().cpu().numpy().copy()
         th = eng.thetaT.cpu().numpy().copy()
         q.put((rank, th, x))
+    finally:
+        dist.destroy_process_group()
+
+
+def hugewiki_worker(rank, world, port, split_dir, n, f, lam, iters, solver, q):
+    """One rank of cumf_als_amd.hugewiki.run on CPU (gloo) with the oracle stand-in ops."""
+    import os
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cumf_als_amd import hugewiki
+
+        eng, log = hugewiki.run(split_dir, n, f, lam, iters, solver=solver, ops=OracleOps(), quiet=True)
+        q.put((rank, eng.thetaT.numpy().copy(), eng.full_XT().numpy().copy(), log))
     finally:
         dist.destroy_process_group()

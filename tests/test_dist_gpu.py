@@ -70,3 +70,24 @@ def test_local_slab_reduce_single_rank(oracle, alslib, solver):
     cp, ri, cv = cdist.local_csc_of_slab_torch(r.csr_indptr, r.csr_indices, r.csr_data, n)
     assert np.array_equal(cp, d["csc_indptr"]) and np.array_equal(ri.cpu().numpy(), d["csc_indices"])
     assert np.array_equal(cv.cpu().numpy(), d["csc_data"])
+
+
+def test_hugewiki_runner_single_gpu(oracle, alslib, tmp_path):
+    """convert split (1 slab) -> cumf_als_amd.hugewiki.run with the HIP kernels: the RMSE log of the
+    reduce scheme agrees with the oracle's doALS (exact test grid) to 1e-4."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    from cumf_als_amd import convert, datagen, hugewiki
+
+    m, n, f, lam, iters = 300, 120, 20, 0.05, 3
+    r = datagen.synth_ratings(m, n, 15000, 1500, seed=13, device="cpu")
+    d = r.numpy()
+    datagen.write_dataset(r, str(tmp_path / "d"))
+    convert.split_dataset(str(tmp_path / "d"), str(tmp_path / "s"), 1, m, n, r.nnz, r.nnz_test)
+    th0, x0 = oracle.init_factors(m, n, f)
+    _, log_o = oracle.do_als(d, th0, x0, m, n, f, lam, iters, solver="lu", test_grid_compat=False)
+    torch.cuda.set_device(0)
+    eng, log = hugewiki.run(str(tmp_path / "s"), n, f, lam, iters, solver="lu", quiet=True)
+    assert np.abs(np.array(log) - np.asarray(log_o)).max() <= 1e-4, (log, log_o)
+    assert np.abs(eng.thetaT.cpu().numpy() - th0.reshape(n, f)).max() <= 2e-3 * np.abs(th0).max()
