@@ -29,3 +29,6 @@ run("netflix", 100, "lu")
 run("netflix", 100, "lu", fused=False, theta_batch=3)
 run("netflix", 200, "cg", fused=False, theta_batch=10)
 run("netflix", 200, "lu", fused=False, theta_batch=10, iters=1)
+run("netflix", 200, "lu", iters=1)
+run("netflix", 128, "lu")
+run("netflix", 128, "cg")
