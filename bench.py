@@ -32,6 +32,7 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -271,6 +272,11 @@ def main() -> int:
             "reduce_kernel_ms_x_side": sum(red_ms[0::2]) / len(red_ms[0::2]),
             "gram_flops_per_launch": float(nnz) * f * (f + 1),
             "gram_tflops": float(nnz) * f * (f + 1) / (avg_ms * 1e-3) / 1e12,
+            # the kernel is co-limited (25 flop/B vs a ridge of ~19.7): the same launch
+            # against the fp32 MFMA roof (algorithmic flops of the symmetric Gram, FMA = 2)
+            "mfma": {"bound": "mfma", "achieved": float(nnz) * f * (f + 1) / (avg_ms * 1e-3) / 1e12,
+                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": float(nnz) * f * (f + 1) / (avg_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS},
         }
         tr, te = eng.rmse()
         out["rmse"] = {"train": tr, "test": te, "after_iterations": a.warmup + a.steps + len(x_ms)}

@@ -54,6 +54,15 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #endif
 
 
+#ifndef CUMF_LU_MFMA
+#define CUMF_LU_MFMA 1  // 0: fused LU through the LDS hand-over + lu_solve_reg (the previous path)
+#endif
+constexpr bool kLuOnAccumulators = CUMF_LU_MFMA != 0;
+#ifndef CUMF_RR_TILES
+#define CUMF_RR_TILES 1
+#endif
+constexpr bool kRoundRobinTiles = CUMF_RR_TILES != 0;
+
 #ifndef CUMF_VARIANT_A
 #define CUMF_VARIANT_A 0  // ablation switches of tools/lu_variants.sh (timing experiments; results are wrong)
 #endif
@@ -70,6 +79,11 @@ struct Geo {
   // (lane = 16*kk + c reads stage[4g+kk][16B+c]) conflict-free for ds_read_b32,
   // whose lane groups are {0-31},{32-63} over 32 banks.
   static constexpr int LD = 16 * NB + ((NB % 2 == 0) ? 16 : 0);
+  // Tile held in accumulator slot s of wave role W.  Round-robin: every role keeps a similar
+  // share of live tiles all through the elimination of lu_solve_mfma (with contiguous ranges the
+  // last role owns the tiles that stay live to the end); the price is that every role reads all
+  // NB feature blocks in the Gram pass.
+  __host__ __device__ static constexpr int tile(int W, int s) { return kRoundRobinTiles ? W + 4 * s : W * TPW + s; }
 };
 
 // Row-major enumeration of the upper triangle: t -> (I, J), I <= J < NB.
@@ -245,7 +259,7 @@ __device__ __forceinline__ void mma_group(const float (&blk)[NB], f32x4 (&acc)[G
   constexpr int NT = Geo<NB>::NT, TPW = Geo<NB>::TPW;
   static_for<TPW>([&](auto sc) {
     constexpr int s = decltype(sc)::value;
-    constexpr int t = W * TPW + s;
+    constexpr int t = Geo<NB>::tile(W, s);
     if constexpr (t < NT) {
       constexpr int I = tile_I<NB>(t), J = tile_J<NB>(t);
       acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(blk[I], blk[J], acc[s], 0, 0, 0);
@@ -313,7 +327,7 @@ __device__ __forceinline__ void tiles_to_tiled(const f32x4 (&acc)[Geo<NB>::TPW],
   const int c = lane & 15, kk = lane >> 4;
   static_for<TPW>([&](auto sc) {
     constexpr int s = decltype(sc)::value;
-    constexpr int t = W * TPW + s;
+    constexpr int t = Geo<NB>::tile(W, s);
     if constexpr (t < NT) {
       constexpr int I = tile_I<NB>(t), J = tile_J<NB>(t);
 #pragma unroll
@@ -335,7 +349,7 @@ __device__ __forceinline__ void tiles_to_lds(const f32x4 (&acc)[Geo<NB>::TPW], f
   const int c = lane & 15, kk = lane >> 4;
   static_for<TPW>([&](auto sc) {
     constexpr int s = decltype(sc)::value;
-    constexpr int t = W * TPW + s;
+    constexpr int t = Geo<NB>::tile(W, s);
     if constexpr (t < NT) {
       constexpr int I = tile_I<NB>(t), J = tile_J<NB>(t);
 #pragma unroll
@@ -359,7 +373,7 @@ __device__ __forceinline__ void tiles_to_global(const f32x4 (&acc)[Geo<NB>::TPW]
   const int c = lane & 15, kk = lane >> 4;
   static_for<TPW>([&](auto sc) {
     constexpr int s = decltype(sc)::value;
-    constexpr int t = W * TPW + s;
+    constexpr int t = Geo<NB>::tile(W, s);
     if constexpr (t < NT) {
       constexpr int I = tile_I<NB>(t), J = tile_J<NB>(t);
 #pragma unroll
@@ -386,7 +400,7 @@ __device__ __forceinline__ void tiles_to_partial(const f32x4 (&acc)[Geo<NB>::TPW
   constexpr int NT = Geo<NB>::NT, TPW = Geo<NB>::TPW;
   static_for<TPW>([&](auto sc) {
     constexpr int s = decltype(sc)::value;
-    constexpr int t = W * TPW + s;
+    constexpr int t = Geo<NB>::tile(W, s);
     if constexpr (t < NT) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) part[((size_t)t * 4 + r) * 64 + lane] = acc[s][r];
@@ -399,7 +413,7 @@ __device__ __forceinline__ void partial_accumulate(f32x4 (&acc)[Geo<NB>::TPW], c
   constexpr int NT = Geo<NB>::NT, TPW = Geo<NB>::TPW;
   static_for<TPW>([&](auto sc) {
     constexpr int s = decltype(sc)::value;
-    constexpr int t = W * TPW + s;
+    constexpr int t = Geo<NB>::tile(W, s);
     if constexpr (t < NT) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[s][r] += part[((size_t)t * 4 + r) * 64 + lane];
@@ -770,6 +784,194 @@ __device__ __forceinline__ void lu_solve_reg(Load load, float* __restrict__ U, i
 #endif
 }
 
+// ----------------------------------------------------------------------------------
+// LU directly on the MFMA accumulators (the fused kernels' LU path).
+//
+// After the Gram pass wave W holds tiles [W*TPW, (W+1)*TPW) of the upper triangle of [A | b] in
+// the 16x16x4 C/D layout (lane (kk, c) = (l >> 4, l & 15), register r: element
+// (16 I + 4 kk + r, 16 J + c)).  The elimination keeps them there and applies FOUR pivots per
+// step as one rank-4 MFMA per tile:
+//   1. the lanes holding the panel rows p0 .. p0+3 (block row Ip, lane group kk = q) publish them
+//      raw -- updated by all earlier panels -- into the packed row store U; ONE barrier;
+//   2. every wave reads the 4x4 pivot block and eliminates it redundantly (multipliers m_kq,
+//      reciprocals 1/u_kk), then per live feature block b >= Ip reads the four raw rows at its
+//      column and forms the eliminated row of ITS lane group, ub[b] = U'[kk][16 b + c];
+//   3. A operand of tile (I, J) = -ub[I] / u_kk masked to rows below the pivot (by symmetry
+//      a_i,pk = u'_k,i), B operand = ub[J]:  acc -= L21 * U12  in one v_mfma_f32_16x16x4_f32;
+//   4. wave 0 stores the eliminated rows (final rows of U) into the row store after the NEXT
+//      barrier, when nobody reads the raw copies any more.
+// Compared with lu_solve_reg: no hand-over of the tiles through LDS, a quarter of the barriers,
+// the trailing update on the otherwise idle matrix pipe.  Unpivoted Gaussian elimination as
+// before (the content of getrfBatched(Pivot = NULL) + getrs); operation order differs from the
+// oracle's, parity is by tolerance (tests/test_gpu_parity.py).
+// ----------------------------------------------------------------------------------
+// Does wave W need the eliminated panel row at feature block b while block row Ip is being
+// eliminated?  Yes if one of its live tiles (I >= Ip) has b as its row or column block; wave 0
+// additionally finalises the panel rows (all live blocks).
+template <int NB>
+__host__ __device__ constexpr bool lu_needs_block(int W, int Ip, int b) {
+  constexpr int NT = Geo<NB>::NT, TPW = Geo<NB>::TPW;
+  if (b < Ip) return false;
+  if (W == 0) return true;
+  for (int s = 0; s < TPW; ++s) {
+    const int t = Geo<NB>::tile(W, s);
+    if (t < NT && tile_I<NB>(t) >= Ip && (tile_I<NB>(t) == b || tile_J<NB>(t) == b)) return true;
+  }
+  return false;
+}
+template <int NB>
+__host__ __device__ constexpr bool lu_wave_live(int W, int Ip) {
+  for (int b = 0; b < NB; ++b)
+    if (lu_needs_block<NB>(W, Ip, b)) return true;
+  return false;
+}
+
+template <int NB, int W>
+__device__ __forceinline__ void lu_solve_mfma(f32x4 (&acc)[Geo<NB>::TPW], float* __restrict__ U,
+                                              float* __restrict__ rdiag, int f, float reg,
+                                              float* __restrict__ x_global, int tid) {
+  constexpr int NT = Geo<NB>::NT, TPW = Geo<NB>::TPW;
+  const int lane = tid & 63, c = lane & 15, kk = lane >> 4;
+  // lambda * n_u on the diagonal (als.cu:545-557)
+  static_for<TPW>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    constexpr int t = Geo<NB>::tile(W, s);
+    if constexpr (t < NT) {
+      if constexpr (tile_I<NB>(t) == tile_J<NB>(t)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (4 * kk + r == c) acc[s][r] += reg;
+      }
+    }
+  });
+  float fin[NB];  // wave 0: eliminated rows of the previous panel at this lane's (row kk, columns 16 b + c)
+  int fin_p0 = -1;
+  auto write_fin = [&]() {  // rows fin_p0 + kk, blocks from the panel's own block row on
+    if constexpr (W == 0) {
+      if (fin_p0 >= 0 && fin_p0 + kk < f) {
+        float* w = U + lu_row_off<NB>(fin_p0 + kk) + c;
+        const int b0 = fin_p0 >> 4;
+        static_for<NB>([&](auto bc) {
+          constexpr int b = decltype(bc)::value;
+          if (b >= b0 && (b < NB - 1 || 16 * b + c <= f)) w[16 * b] = fin[b];
+        });
+      }
+    }
+  };
+
+  static_for<NB>([&](auto ipc) {
+    constexpr int Ip = decltype(ipc)::value;
+    for (int q = 0; q < 4; ++q) {
+      const int p0 = 16 * Ip + 4 * q;
+      if (p0 >= f) break;
+      // 1. publish the raw panel rows (tiles of block row Ip, lane group q)
+      static_for<TPW>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        constexpr int t = Geo<NB>::tile(W, s);
+        if constexpr (t < NT) {
+          if constexpr (tile_I<NB>(t) == Ip) {
+            constexpr int J = tile_J<NB>(t);
+            if (kk == q && (J < NB - 1 || 16 * J + c <= f)) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (p0 + r < f) U[lu_row_off<NB>(p0 + r) + 16 * J + c] = acc[s][r];
+            }
+          }
+        }
+      });
+      __syncthreads();
+      // 4. (of the previous panel) final rows into the store
+      write_fin();
+      if constexpr (lu_wave_live<NB>(W, Ip)) {
+      // 2a. pivot block, eliminated redundantly in every lane
+      const float* r0p = U + lu_row_off<NB>(p0);
+      const float* r1p = U + lu_row_off<NB>(p0 + 1 < f ? p0 + 1 : p0);
+      const float* r2p = U + lu_row_off<NB>(p0 + 2 < f ? p0 + 2 : p0);
+      const float* r3p = U + lu_row_off<NB>(p0 + 3 < f ? p0 + 3 : p0);
+      const bool v1 = p0 + 1 < f, v2 = p0 + 2 < f, v3 = p0 + 3 < f;
+      float P00 = r0p[p0], P01 = r0p[p0 + 1], P02 = r0p[p0 + 2], P03 = r0p[p0 + 3];
+      float P11 = r1p[p0 + 1], P12 = r1p[p0 + 2], P13 = r1p[p0 + 3];
+      float P22 = r2p[p0 + 2], P23 = r2p[p0 + 3];
+      float P33 = r3p[p0 + 3];
+      // v_rcp_f32 is accurate to 1 ulp; the four reciprocals are a dependent chain, so no Newton step
+      auto recip = [](float d) { return __builtin_amdgcn_rcpf(d); };
+      const float rp0 = recip(P00);
+      const float m10 = -P01 * rp0, m20 = -P02 * rp0, m30 = -P03 * rp0;  // -(multiplier of row k w.r.t. pivot 0)
+      P11 = fmaf(m10, P01, P11);
+      P12 = fmaf(m10, P02, P12);
+      P13 = fmaf(m10, P03, P13);
+      P22 = fmaf(m20, P02, P22);
+      P23 = fmaf(m20, P03, P23);
+      P33 = fmaf(m30, P03, P33);
+      const float rp1 = recip(v1 ? P11 : 1.0f);
+      const float m21 = -P12 * rp1, m31 = -P13 * rp1;
+      P22 = fmaf(m21, P12, P22);
+      P23 = fmaf(m21, P13, P23);
+      P33 = fmaf(m31, P13, P33);
+      const float rp2 = recip(v2 ? P22 : 1.0f);
+      const float m32 = -P23 * rp2;
+      P33 = fmaf(m32, P23, P33);
+      const float rp3 = recip(v3 ? P33 : 1.0f);
+      if constexpr (W == 0) {
+        if (lane < 4) {
+          const float mine = lane == 0 ? rp0 : (lane == 1 ? rp1 : (lane == 2 ? rp2 : rp3));
+          if (p0 + lane < f) rdiag[p0 + lane] = mine;
+        }
+      }
+      // this lane group's pivot: valid?  -1/u_kk
+      const bool vk = p0 + kk < f;
+      const float nrp = vk ? -(kk == 0 ? rp0 : (kk == 1 ? rp1 : (kk == 2 ? rp2 : rp3))) : 0.f;
+      // 2b. eliminated panel row of this lane group at every live block.  Row k of the panel after
+      // the elimination is raw_k + sum_{q<k} e_kq raw_q with the composite multipliers e (the rows
+      // of the inverse of the panel's unit lower triangle): three FMAs per block instead of the
+      // six of the step-by-step elimination of all four rows in every lane.
+      const float e20 = fmaf(m21, m10, m20);
+      const float e31 = fmaf(m32, m21, m31);
+      const float e30 = fmaf(m32, e20, fmaf(m31, m10, m30));
+      const float c0 = kk == 1 ? m10 : (kk == 2 ? e20 : (kk == 3 ? e30 : 0.f));
+      const float c1 = kk == 2 ? m21 : (kk == 3 ? e31 : 0.f);
+      const float c2 = kk == 3 ? m32 : 0.f;
+      const float* rkp = U + lu_row_off<NB>(vk ? p0 + kk : p0);
+      float ub[NB];
+      static_for<NB>([&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        if constexpr (lu_needs_block<NB>(W, Ip, b)) {
+          const float own = rkp[16 * b + c];
+          const float a0 = r0p[16 * b + c], a1 = r1p[16 * b + c], a2 = r2p[16 * b + c];
+          // lanes of a pivot past f (short last panel) keep a finite dummy: their A operand is 0
+          ub[b] = fmaf(c2, a2, fmaf(c1, a1, fmaf(c0, a0, own)));
+        }
+      });
+      // 3. rank-4 update of the live tiles
+      static_for<TPW>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        constexpr int t = Geo<NB>::tile(W, s);
+        if constexpr (t < NT) {
+          constexpr int I = tile_I<NB>(t), J = tile_J<NB>(t);
+          if constexpr (I >= Ip) {
+            float la = ub[I] * nrp;
+            if constexpr (I == Ip) la = (c > 4 * q + kk) ? la : 0.f;  // rows at or above the pivot stay
+            acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(la, ub[J], acc[s], 0, 0, 0);
+          }
+        }
+      });
+      // 4. remember the eliminated rows
+      if constexpr (W == 0) {
+        static_for<NB>([&](auto bc) {
+          constexpr int b = decltype(bc)::value;
+          if constexpr (b >= Ip) fin[b] = ub[b];
+        });
+        fin_p0 = p0;
+      }
+      }  // lu_wave_live
+    }
+  });
+  __syncthreads();
+  write_fin();
+  __syncthreads();
+  if constexpr (W == 0) back_substitute_fast<NB, (16 * NB + 63) / 64>(U, f, rdiag, x_global, lane);
+}
+
 // Loaders of lu_solve_reg.  TileLoad: the accumulator tiles parked in LDS by tiles_to_tiled.
 template <int NB>
 struct TileLoad {
@@ -821,8 +1023,21 @@ __device__ __forceinline__ void dump_row(const f32x4 (&acc)[Geo<NB>::TPW], float
   }
 }
 
+// LU (default build): the whole solve runs on the accumulators inside the wave roles.
+template <int NB, int MODE, int W>
+__device__ __forceinline__ void finish_row(f32x4 (&acc)[Geo<NB>::TPW], float* smem, const KernelArgs& a, int row,
+                                           int rowlen, int tid) {
+  if constexpr (MODE == kModeLU && kLuOnAccumulators) {
+    lu_solve_mfma<NB, W>(acc, smem, smem + lu_packed_floats(NB), a.f, (float)rowlen * a.lambda,
+                         a.update + (size_t)row * a.f, tid);
+  } else {
+    dump_row<NB, MODE, W>(acc, smem, a, row, rowlen, tid & 63);
+  }
+}
+
 template <int NB, int MODE>
 __device__ __forceinline__ void solve_row(float* smem, const KernelArgs& a, int row, int tid) {
+  if constexpr (MODE == kModeLU && kLuOnAccumulators) return;  // done in finish_row
   if constexpr (MODE != kModeMaterialize) {
     const int f = a.f, ldg = solve_ldg(f, MODE);
     float* G = smem;
@@ -945,7 +1160,7 @@ __device__ __forceinline__ void item_body(float* smem, const KernelArgs& a, int 
   if (slot >= 0)
     tiles_to_partial<NB, W>(acc, a.part + (size_t)slot * Geo<NB>::NT * 256, lane);
   else
-    dump_row<NB, MODE, W>(acc, smem, a, row, rowlen, lane);
+    finish_row<NB, MODE, W>(acc, smem, a, row, rowlen, tid);
 }
 
 template <int NB, typename VT, int MODE>
@@ -958,7 +1173,12 @@ __global__ __launch_bounds__(kThreads) void als_item_kernel(const KernelArgs a) 
   const int len = a.item_len[item];
   const int slot = a.item_slot[item];
   const int rowlen = a.item_rowlen[item];
-  switch (tid >> 6) {
+  // Role of this wave.  The LU on the accumulators loads the roles unevenly (the last role's tiles
+  // stay live to the end), so the roles are rotated with the workgroup index: workgroups that
+  // share a CU differ in item / 256 (dispatch is round-robin over 8 XCDs x 32 CUs) and their
+  // heavy roles then sit on different SIMDs.
+  const int role = (MODE == kModeLU && kLuOnAccumulators) ? (((tid >> 6) + (item >> 8) + (item >> 10)) & 3) : (tid >> 6);
+  switch (role) {
     case 0: item_body<NB, VT, MODE, 0>(smem, a, row, begin, len, slot, rowlen, tid); break;
     case 1: item_body<NB, VT, MODE, 1>(smem, a, row, begin, len, slot, rowlen, tid); break;
     case 2: item_body<NB, VT, MODE, 2>(smem, a, row, begin, len, slot, rowlen, tid); break;
@@ -980,7 +1200,7 @@ __device__ __forceinline__ void reduce_body(float* smem, const KernelArgs& a, in
   for (int s = 0; s < TPW; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int sl = 0; sl < nslots; ++sl)
     partial_accumulate<NB, W>(acc, a.part + (size_t)(slot0 + sl) * Geo<NB>::NT * 256, lane);
-  dump_row<NB, MODE, W>(acc, smem, a, row, rowlen, lane);
+  finish_row<NB, MODE, W>(acc, smem, a, row, rowlen, lane + 64 * W);
 }
 
 template <int NB, int MODE>
