@@ -608,10 +608,14 @@ __device__ __forceinline__ void lu_solve_lds(float* __restrict__ G, int ldg, int
 // (wave 0).  The recurrence is a chain of f dependent steps, so everything that does not depend
 // on the running vector is moved off it: row i is pre-scaled by 1/u_ii (z_i = y_i / u_ii,
 // v_ik = u_ik / u_ii: unit diagonal, x_k = z_k needs no multiply), the column of step k is
-// fetched kBackDepth steps ahead, masked (rows >= k -> 0) and scaled when it arrives, and the
+// fetched (kBackRing - 1) x kBackDepth steps ahead, masked (rows >= k -> 0) and scaled when it arrives, and the
 // pivots of rows 64.. and 0..63 get their own passes so the readlane register is static.  What
 // is left on the chain per step is one v_readlane and one v_fma.
 constexpr int kBackDepth = 4;
+#ifndef CUMF_BACK_RING
+#define CUMF_BACK_RING 2
+#endif
+constexpr int kBackRing = CUMF_BACK_RING;  // groups of columns in flight
 template <int NB, int NQ>
 __device__ __forceinline__ void back_substitute_fast(const float* __restrict__ U, int f,
                                                      const float* __restrict__ rdiag,
@@ -631,19 +635,20 @@ __device__ __forceinline__ void back_substitute_fast(const float* __restrict__ U
     const int klo = 64 * Q;
     const int top = (f - 1 < klo + 63) ? f - 1 : klo + 63;
     if (top >= klo) {
-      // whole double-groups of 2 x kBackDepth steps, no guards in the loop (a guard is a branch,
-      // and branches make the compiler wait for every outstanding LDS read): the steps above
-      // f-1 that round the count up are no-ops (their column is masked to 0).  While one group
-      // of columns is consumed the other is in flight; the sched_barriers keep the compiler
-      // from sinking the reads next to their use.
-      constexpr int D2 = 2 * kBackDepth;
-      const int khi = klo + ((top - klo + D2) / D2) * D2 - 1;
-      float c[2][kBackDepth][Q + 1];
-      auto issue = [&](auto hc, int kfirst) {  // columns kfirst, kfirst-1, ... into half h
+      // whole rounds of kBackRing groups x kBackDepth steps, no guards in the loop (a guard is a
+      // branch, and branches make the compiler wait for every outstanding LDS read): the steps
+      // above `top` that round the count up are no-ops (their column is masked to 0).  While one
+      // group of columns is consumed the others are in flight; the sched_barriers keep the
+      // compiler from sinking the reads next to their use.
+      constexpr int DR = kBackRing * kBackDepth;
+      const int khi = klo + ((top - klo + DR) / DR) * DR - 1;
+      float c[kBackRing][kBackDepth][Q + 1];
+      auto issue = [&](auto hc, int kfirst) {  // columns kfirst, kfirst-1, ... into group h
         constexpr int h = decltype(hc)::value;
         static_for<kBackDepth>([&](auto jc) {
           constexpr int j = decltype(jc)::value;
-          const int kc = kfirst - j > 0 ? kfirst - j : 0;
+          int kc = kfirst - j > 0 ? kfirst - j : 0;
+          kc = kc <= top ? kc : top;
           static_for<Q + 1>([&](auto qc) { c[h][j][decltype(qc)::value] = rowp[decltype(qc)::value][kc]; });
         });
       };
@@ -652,7 +657,7 @@ __device__ __forceinline__ void back_substitute_fast(const float* __restrict__ U
         static_for<kBackDepth>([&](auto jc) {
           constexpr int j = decltype(jc)::value;
           const int kk = kfirst - j;
-          const int lim = kk < f ? kk : 0;  // rows below the pivot take part; none for a padding step
+          const int lim = kk <= top ? kk : 0;  // rows below the pivot take part; none for a padding step
           float v[Q + 1];
           static_for<Q + 1>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
@@ -666,16 +671,15 @@ __device__ __forceinline__ void back_substitute_fast(const float* __restrict__ U
           });
         });
       };
-      issue(std::integral_constant<int, 0>{}, khi);
-      issue(std::integral_constant<int, 1>{}, khi - kBackDepth);
+      static_for<kBackRing>([&](auto gc) { issue(gc, khi - decltype(gc)::value * kBackDepth); });
       __builtin_amdgcn_sched_barrier(0);
-      for (int k = khi; k >= klo; k -= D2) {
-        consume(std::integral_constant<int, 0>{}, k);
-        issue(std::integral_constant<int, 0>{}, k - D2);
-        __builtin_amdgcn_sched_barrier(0);
-        consume(std::integral_constant<int, 1>{}, k - kBackDepth);
-        issue(std::integral_constant<int, 1>{}, k - D2 - kBackDepth);
-        __builtin_amdgcn_sched_barrier(0);
+      for (int k = khi; k >= klo; k -= DR) {
+        static_for<kBackRing>([&](auto gc) {
+          constexpr int g = decltype(gc)::value;
+          consume(gc, k - g * kBackDepth);
+          issue(gc, k - DR - g * kBackDepth);
+          __builtin_amdgcn_sched_barrier(0);
+        });
       }
     }
   });
@@ -864,6 +868,9 @@ __device__ __forceinline__ void lu_solve_mfma(f32x4 (&acc)[Geo<NB>::TPW], float*
     for (int q = 0; q < 4; ++q) {
       const int p0 = 16 * Ip + 4 * q;
       if (p0 >= f) break;
+#if CUMF_VARIANT_A & 32
+      if (p0 >= 0) break;
+#endif
       // 1. publish the raw panel rows (tiles of block row Ip, lane group q)
       static_for<TPW>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
@@ -939,7 +946,12 @@ __device__ __forceinline__ void lu_solve_mfma(f32x4 (&acc)[Geo<NB>::TPW], float*
           const float own = rkp[16 * b + c];
           const float a0 = r0p[16 * b + c], a1 = r1p[16 * b + c], a2 = r2p[16 * b + c];
           // lanes of a pivot past f (short last panel) keep a finite dummy: their A operand is 0
+#if CUMF_VARIANT_A & 64
+          ub[b] = own + c0 + c1 + c2;
+          (void)a0; (void)a1; (void)a2;
+#else
           ub[b] = fmaf(c2, a2, fmaf(c1, a1, fmaf(c0, a0, own)));
+#endif
         }
       });
       // 3. rank-4 update of the live tiles
@@ -951,7 +963,11 @@ __device__ __forceinline__ void lu_solve_mfma(f32x4 (&acc)[Geo<NB>::TPW], float*
           if constexpr (I >= Ip) {
             float la = ub[I] * nrp;
             if constexpr (I == Ip) la = (c > 4 * q + kk) ? la : 0.f;  // rows at or above the pivot stay
+#if CUMF_VARIANT_A & 2
+            acc[s][0] += la * ub[J];
+#else
             acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(la, ub[J], acc[s], 0, 0, 0);
+#endif
           }
         }
       });
@@ -969,7 +985,9 @@ __device__ __forceinline__ void lu_solve_mfma(f32x4 (&acc)[Geo<NB>::TPW], float*
   __syncthreads();
   write_fin();
   __syncthreads();
+#if !(CUMF_VARIANT_A & 8)
   if constexpr (W == 0) back_substitute_fast<NB, (16 * NB + 63) / 64>(U, f, rdiag, x_global, lane);
+#endif
 }
 
 // Loaders of lu_solve_reg.  TileLoad: the accumulator tiles parked in LDS by tiles_to_tiled.

@@ -11,7 +11,7 @@ if [ "$1" = build ]; then
   for v in $2; do
     M=${v%%:*}; A=${v##*:}
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form \
-      -DCUMF_VARIANT_M=$M -DCUMF_VARIANT_A=$A -Iinclude -I$C -DCUMF_ONLY_NB=${NBONLY:-7} -c $C/als_kernels.hip -o variants/k_${M}_${A}.o
+      -DCUMF_BACK_RING=$M -DCUMF_VARIANT_A=$A -Iinclude -I$C -DCUMF_ONLY_NB=${NBONLY:-7} -c $C/als_kernels.hip -o variants/k_${M}_${A}.o
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/libALS_${M}_${A}.so variants/k_${M}_${A}.o \
       $C/als_plan.o $C/als_driver.o $C/host_utilities.o
     rm variants/k_${M}_${A}.o
