@@ -57,7 +57,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef CUMF_LU_MFMA
 #define CUMF_LU_MFMA 1  // 0: fused LU through the LDS hand-over + lu_solve_reg (the previous path)
 #endif
-constexpr bool kLuOnAccumulators = CUMF_LU_MFMA != 0;
+// The accumulator LU pays off from f = 96 on (measured: f = 64 18.8 vs 18.0 ms, f = 10 0.67 vs 0.56 ms with
+// the thread-grid LU; f = 100 35.7 vs 36.8, f = 128 62.2 vs 63.8, f = 200 200 vs 224).
+constexpr bool lu_on_accumulators(int nb) { return CUMF_LU_MFMA != 0 && nb >= 7; }
 #ifndef CUMF_RR_TILES
 #define CUMF_RR_TILES 1
 #endif
@@ -83,7 +85,9 @@ struct Geo {
   // share of live tiles all through the elimination of lu_solve_mfma (with contiguous ranges the
   // last role owns the tiles that stay live to the end); the price is that every role reads all
   // NB feature blocks in the Gram pass.
-  __host__ __device__ static constexpr int tile(int W, int s) { return kRoundRobinTiles ? W + 4 * s : W * TPW + s; }
+  __host__ __device__ static constexpr int tile(int W, int s) {
+    return (kRoundRobinTiles && NB >= 7) ? W + 4 * s : W * TPW + s;
+  }
 };
 
 // Row-major enumeration of the upper triangle: t -> (I, J), I <= J < NB.
@@ -1045,7 +1049,7 @@ __device__ __forceinline__ void dump_row(const f32x4 (&acc)[Geo<NB>::TPW], float
 template <int NB, int MODE, int W>
 __device__ __forceinline__ void finish_row(f32x4 (&acc)[Geo<NB>::TPW], float* smem, const KernelArgs& a, int row,
                                            int rowlen, int tid) {
-  if constexpr (MODE == kModeLU && kLuOnAccumulators) {
+  if constexpr (MODE == kModeLU && lu_on_accumulators(NB)) {
     lu_solve_mfma<NB, W>(acc, smem, smem + lu_packed_floats(NB), a.f, (float)rowlen * a.lambda,
                          a.update + (size_t)row * a.f, tid);
   } else {
@@ -1055,7 +1059,7 @@ __device__ __forceinline__ void finish_row(f32x4 (&acc)[Geo<NB>::TPW], float* sm
 
 template <int NB, int MODE>
 __device__ __forceinline__ void solve_row(float* smem, const KernelArgs& a, int row, int tid) {
-  if constexpr (MODE == kModeLU && kLuOnAccumulators) return;  // done in finish_row
+  if constexpr (MODE == kModeLU && lu_on_accumulators(NB)) return;  // done in finish_row
   if constexpr (MODE != kModeMaterialize) {
     const int f = a.f, ldg = solve_ldg(f, MODE);
     float* G = smem;
@@ -1195,7 +1199,8 @@ __global__ __launch_bounds__(kThreads) void als_item_kernel(const KernelArgs a) 
   // stay live to the end), so the roles are rotated with the workgroup index: workgroups that
   // share a CU differ in item / 256 (dispatch is round-robin over 8 XCDs x 32 CUs) and their
   // heavy roles then sit on different SIMDs.
-  const int role = (MODE == kModeLU && kLuOnAccumulators) ? (((tid >> 6) + (item >> 8) + (item >> 10)) & 3) : (tid >> 6);
+  const int role =
+      (MODE == kModeLU && lu_on_accumulators(NB)) ? (((tid >> 6) + (item >> 8) + (item >> 10)) & 3) : (tid >> 6);
   switch (role) {
     case 0: item_body<NB, VT, MODE, 0>(smem, a, row, begin, len, slot, rowlen, tid); break;
     case 1: item_body<NB, VT, MODE, 1>(smem, a, row, begin, len, slot, rowlen, tid); break;
