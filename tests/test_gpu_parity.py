@@ -117,7 +117,7 @@ def test_cg_solve(oracle, alslib, f):
 
 
 @pytest.mark.parametrize("solver,f", [("cg", 10), ("cg", 100), ("cg", 128), ("lu", 10), ("lu", 100), ("lu", 128),
-                                      ("lu", 200)])
+                                      ("lu", 200), ("lu", 98), ("lu", 110), ("lu", 96), ("lu", 206), ("cg", 98)])
 def test_fused_half_iteration(oracle, alslib, solver, f):
     _need_gpu()
     from cumf_als_amd import als
