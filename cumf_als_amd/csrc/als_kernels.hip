@@ -834,6 +834,18 @@ __host__ __device__ constexpr bool lu_wave_live(int W, int Ip) {
   return false;
 }
 
+// Role that holds the diagonal tile of block row Ip.
+template <int NB>
+__host__ __device__ constexpr int lu_diag_owner(int Ip) {
+  constexpr int NT = Geo<NB>::NT, TPW = Geo<NB>::TPW;
+  for (int W = 0; W < 4; ++W)
+    for (int s = 0; s < TPW; ++s) {
+      const int t = Geo<NB>::tile(W, s);
+      if (t < NT && tile_I<NB>(t) == Ip && tile_J<NB>(t) == Ip) return W;
+    }
+  return 0;
+}
+
 template <int NB, int W>
 __device__ __forceinline__ void lu_solve_mfma(f32x4 (&acc)[Geo<NB>::TPW], float* __restrict__ U,
                                               float* __restrict__ rdiag, int f, float reg,
@@ -852,6 +864,7 @@ __device__ __forceinline__ void lu_solve_mfma(f32x4 (&acc)[Geo<NB>::TPW], float*
       }
     }
   });
+  float* ctab = rdiag + ((f + 3) & ~3);  // 2 x 16 floats, 16-byte aligned
   float fin[NB];  // wave 0: eliminated rows of the previous panel at this lane's (row kk, columns 16 b + c)
   int fin_p0 = -1;
   auto write_fin = [&]() {  // rows fin_p0 + kk, blocks from the panel's own block row on
@@ -890,58 +903,71 @@ __device__ __forceinline__ void lu_solve_mfma(f32x4 (&acc)[Geo<NB>::TPW], float*
           }
         }
       });
+      // 2a. the role that owns the diagonal tile of block row Ip has just written the 4x4 pivot
+      // block: it alone eliminates it (four dependent reciprocals, no division) and leaves, per
+      // lane group kk, the composite multipliers (c0, c1, c2) of panel row kk and -1/u_kk in a
+      // 16-float table (double-buffered by panel parity) -- the other roles just read their line.
+      // Row k of the panel after the elimination is raw_k + sum_{q<k} e_kq raw_q with e = the rows
+      // of the inverse of the panel's unit lower triangle.
+      const bool vk = p0 + kk < f;  // this lane group's pivot exists (short last panel otherwise)
+      float* tab = ctab + 16 * ((p0 >> 2) & 1);
+      float c0 = 0.f, c1 = 0.f, c2 = 0.f, nrp = 0.f;
+      constexpr int OWNER = lu_diag_owner<NB>(Ip);
+      if constexpr (W == OWNER) {
+        const float* o0 = U + lu_row_off<NB>(p0);
+        const float* o1 = U + lu_row_off<NB>(p0 + 1 < f ? p0 + 1 : p0);
+        const float* o2 = U + lu_row_off<NB>(p0 + 2 < f ? p0 + 2 : p0);
+        const float* o3 = U + lu_row_off<NB>(p0 + 3 < f ? p0 + 3 : p0);
+        const bool v1 = p0 + 1 < f, v2 = p0 + 2 < f, v3 = p0 + 3 < f;
+        float P00 = o0[p0], P01 = o0[p0 + 1], P02 = o0[p0 + 2], P03 = o0[p0 + 3];
+        float P11 = o1[p0 + 1], P12 = o1[p0 + 2], P13 = o1[p0 + 3];
+        float P22 = o2[p0 + 2], P23 = o2[p0 + 3];
+        float P33 = o3[p0 + 3];
+        // v_rcp_f32 is accurate to 1 ulp; the four reciprocals are a dependent chain, so no Newton step
+        auto recip = [](float d) { return __builtin_amdgcn_rcpf(d); };
+        const float rp0 = recip(P00);
+        const float m10 = -P01 * rp0, m20 = -P02 * rp0, m30 = -P03 * rp0;  // -(multiplier of row k w.r.t. pivot 0)
+        P11 = fmaf(m10, P01, P11);
+        P12 = fmaf(m10, P02, P12);
+        P13 = fmaf(m10, P03, P13);
+        P22 = fmaf(m20, P02, P22);
+        P23 = fmaf(m20, P03, P23);
+        P33 = fmaf(m30, P03, P33);
+        const float rp1 = recip(v1 ? P11 : 1.0f);
+        const float m21 = -P12 * rp1, m31 = -P13 * rp1;
+        P22 = fmaf(m21, P12, P22);
+        P23 = fmaf(m21, P13, P23);
+        P33 = fmaf(m31, P13, P33);
+        const float rp2 = recip(v2 ? P22 : 1.0f);
+        const float m32 = -P23 * rp2;
+        P33 = fmaf(m32, P23, P33);
+        const float rp3 = recip(v3 ? P33 : 1.0f);
+        const float e20 = fmaf(m21, m10, m20);
+        const float e31 = fmaf(m32, m21, m31);
+        const float e30 = fmaf(m32, e20, fmaf(m31, m10, m30));
+        const float rpk = kk == 0 ? rp0 : (kk == 1 ? rp1 : (kk == 2 ? rp2 : rp3));
+        c0 = kk == 1 ? m10 : (kk == 2 ? e20 : (kk == 3 ? e30 : 0.f));
+        c1 = kk == 2 ? m21 : (kk == 3 ? e31 : 0.f);
+        c2 = kk == 3 ? m32 : 0.f;
+        nrp = vk ? -rpk : 0.f;
+        if (c < 4) tab[4 * kk + c] = c == 0 ? c0 : (c == 1 ? c1 : (c == 2 ? c2 : nrp));
+        if (c == 4 && vk) rdiag[p0 + kk] = rpk;
+      }
       __syncthreads();
       // 4. (of the previous panel) final rows into the store
       write_fin();
       if constexpr (lu_wave_live<NB>(W, Ip)) {
-      // 2a. pivot block, eliminated redundantly in every lane
       const float* r0p = U + lu_row_off<NB>(p0);
       const float* r1p = U + lu_row_off<NB>(p0 + 1 < f ? p0 + 1 : p0);
       const float* r2p = U + lu_row_off<NB>(p0 + 2 < f ? p0 + 2 : p0);
-      const float* r3p = U + lu_row_off<NB>(p0 + 3 < f ? p0 + 3 : p0);
-      const bool v1 = p0 + 1 < f, v2 = p0 + 2 < f, v3 = p0 + 3 < f;
-      float P00 = r0p[p0], P01 = r0p[p0 + 1], P02 = r0p[p0 + 2], P03 = r0p[p0 + 3];
-      float P11 = r1p[p0 + 1], P12 = r1p[p0 + 2], P13 = r1p[p0 + 3];
-      float P22 = r2p[p0 + 2], P23 = r2p[p0 + 3];
-      float P33 = r3p[p0 + 3];
-      // v_rcp_f32 is accurate to 1 ulp; the four reciprocals are a dependent chain, so no Newton step
-      auto recip = [](float d) { return __builtin_amdgcn_rcpf(d); };
-      const float rp0 = recip(P00);
-      const float m10 = -P01 * rp0, m20 = -P02 * rp0, m30 = -P03 * rp0;  // -(multiplier of row k w.r.t. pivot 0)
-      P11 = fmaf(m10, P01, P11);
-      P12 = fmaf(m10, P02, P12);
-      P13 = fmaf(m10, P03, P13);
-      P22 = fmaf(m20, P02, P22);
-      P23 = fmaf(m20, P03, P23);
-      P33 = fmaf(m30, P03, P33);
-      const float rp1 = recip(v1 ? P11 : 1.0f);
-      const float m21 = -P12 * rp1, m31 = -P13 * rp1;
-      P22 = fmaf(m21, P12, P22);
-      P23 = fmaf(m21, P13, P23);
-      P33 = fmaf(m31, P13, P33);
-      const float rp2 = recip(v2 ? P22 : 1.0f);
-      const float m32 = -P23 * rp2;
-      P33 = fmaf(m32, P23, P33);
-      const float rp3 = recip(v3 ? P33 : 1.0f);
-      if constexpr (W == 0) {
-        if (lane < 4) {
-          const float mine = lane == 0 ? rp0 : (lane == 1 ? rp1 : (lane == 2 ? rp2 : rp3));
-          if (p0 + lane < f) rdiag[p0 + lane] = mine;
-        }
+      if constexpr (W != OWNER) {
+        const f32x4 line = *reinterpret_cast<const f32x4*>(tab + 4 * kk);
+        c0 = line[0];
+        c1 = line[1];
+        c2 = line[2];
+        nrp = line[3];
       }
-      // this lane group's pivot: valid?  -1/u_kk
-      const bool vk = p0 + kk < f;
-      const float nrp = vk ? -(kk == 0 ? rp0 : (kk == 1 ? rp1 : (kk == 2 ? rp2 : rp3))) : 0.f;
-      // 2b. eliminated panel row of this lane group at every live block.  Row k of the panel after
-      // the elimination is raw_k + sum_{q<k} e_kq raw_q with the composite multipliers e (the rows
-      // of the inverse of the panel's unit lower triangle): three FMAs per block instead of the
-      // six of the step-by-step elimination of all four rows in every lane.
-      const float e20 = fmaf(m21, m10, m20);
-      const float e31 = fmaf(m32, m21, m31);
-      const float e30 = fmaf(m32, e20, fmaf(m31, m10, m30));
-      const float c0 = kk == 1 ? m10 : (kk == 2 ? e20 : (kk == 3 ? e30 : 0.f));
-      const float c1 = kk == 2 ? m21 : (kk == 3 ? e31 : 0.f);
-      const float c2 = kk == 3 ? m32 : 0.f;
+      // 2b. eliminated panel row of this lane group at every live block: three FMAs per block
       const float* rkp = U + lu_row_off<NB>(vk ? p0 + kk : p0);
       float ub[NB];
       static_for<NB>([&](auto bc) {
