@@ -1,8 +1,11 @@
 #!/bin/bash
-# Build libALS variants of the register-resident LU (panel height / ablations) into variants/
-# and, with "run", time the batched solve with each (tools/bench_solve.py, LU line only).
-# Usage: tools/lu_variants.sh build "1:0 2:0 4:0 2:1 2:2 2:4 2:8"   (PANEL:ABLATION pairs)
-#        tools/lu_variants.sh run
+# Build libALS variants of the fused LU into variants/ (NB = 7 kernels only, one translation
+# unit, ~40 s each) and time them: RING:ABLATION pairs, RING = prefetch groups of the back
+# substitution (CUMF_BACK_RING), ABLATION = CUMF_VARIANT_A bits (2: no MFMA update, 8: no back
+# substitution, 32: no elimination, 64: no per-block row forming; results are then wrong).
+# Usage: tools/lu_variants.sh build "2:0 2:2 2:8 2:32 2:40 2:64"
+#        tools/lu_variants.sh run            (batched solve only, tools/bench_solve.py)
+#        tools/bench_variants.sh             (bench.py, Netflix f=100, with every variant)
 set -e
 cd "$(dirname "$0")/.."
 C=cumf_als_amd/csrc
