@@ -28,8 +28,8 @@ __host__ __device__ constexpr size_t solve_g_floats(int f, int mode) {
 // pivot reciprocals.  f = 100: 29 520 B, below the 32 256 B of the stage buffers it aliases
 // -> 5 workgroups per CU.
 __host__ __device__ constexpr size_t lu_packed_floats(int nb) { return (size_t)256 * nb * (nb + 1) / 2 + 16 * nb; }
-// + 2 x 16 multipliers of the panel owner (accumulator LU)
-__host__ __device__ constexpr size_t lu_lds_floats(int nb, int f) { return lu_packed_floats(nb) + (size_t)((f + 3) & ~3) + 32; }
+// + 2 x 16 multipliers of the panel owner + 16 zeros (accumulator LU)
+__host__ __device__ constexpr size_t lu_lds_floats(int nb, int f) { return lu_packed_floats(nb) + (size_t)((f + 3) & ~3) + 48; }
 constexpr int kCgExtraFloats = 12 * kVecLd;  // 4 per-wave operand copies + 2 x 4 partial mat-vecs
 // whole LDS footprint of a solve on a full G: G + CG exchange buffers | G (exact-order LU)
 __host__ __device__ constexpr size_t solve_lds_floats(int f, int mode) {

@@ -813,6 +813,77 @@ __device__ __forceinline__ void lu_solve_reg(Load load, float* __restrict__ U, i
 // before (the content of getrfBatched(Pivot = NULL) + getrs); operation order differs from the
 // oracle's, parity is by tolerance (tests/test_gpu_parity.py).
 // ----------------------------------------------------------------------------------
+// Back substitution of the accumulator LU (one wave).  Same recurrence as back_substitute_fast, but
+// organised by 16-pivot blocks on a row store whose entries at or left of the diagonal inside the
+// diagonal blocks are zero (lu_solve_mfma's write_fin): the lanes of the pivot block then need no
+// triangle mask, the lanes of later blocks are pointed at 16 zeros (zpad) once per block, and the
+// 16 columns of a block are read with immediate offsets from one base per lane.  Per step that
+// leaves v_readlane, one packed multiply (the 1/u_ii scaling) and one packed FMA.
+template <int NB, int NQ>
+__device__ __forceinline__ void back_substitute_zeroed(const float* __restrict__ U, int f,
+                                                       const float* __restrict__ rdiag,
+                                                       const float* __restrict__ zpad,
+                                                       float* __restrict__ x_global, int lane) {
+  float z[NQ], rdl[NQ];
+  const float* rowp[NQ];
+  int ib[NQ];  // block of this lane's row
+  static_for<NQ>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    const int i = lane + 64 * q;
+    const int ic = i < f ? i : f - 1;
+    ib[q] = i < f ? (i >> 4) : 1 << 20;  // rows past f never take part
+    rowp[q] = U + lu_row_off<NB>(ic);
+    rdl[q] = i < f ? rdiag[ic] : 0.f;
+    z[q] = rowp[q][f] * rdl[q];
+  });
+  const int top = f - 1;
+  constexpr int NBLK = NB;  // pivot blocks 0 .. (f-1)>>4 <= NB-1
+  // two column buffers: the 16 columns of the next block are in flight while this one is consumed
+  float col[2][16][NQ];
+  auto issue = [&](auto kbc, auto bufc) {
+    constexpr int kb = decltype(kbc)::value, buf = decltype(bufc)::value, Q = kb >> 2;
+    // per lane: the 16 entries of its row in the block's columns (zeros for rows of later blocks)
+    const float* base[Q + 1];
+    static_for<Q + 1>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      base[q] = (ib[q] > kb) ? zpad : rowp[q] + 16 * kb;
+    });
+    static_for<16>([&](auto jc) {  // issued in the order they are consumed (LDS returns in order)
+      constexpr int j = 15 - decltype(jc)::value;
+      static_for<Q + 1>([&](auto qc) { col[buf][j][decltype(qc)::value] = base[decltype(qc)::value][j]; });
+    });
+  };
+  static_for<NBLK>([&](auto bc) {
+    constexpr int n = decltype(bc)::value;
+    constexpr int kb = NBLK - 1 - n;
+    constexpr int buf = n & 1;
+    constexpr int Q = kb >> 2;  // pivots of this block live in z[Q]
+    if constexpr (Q < NQ) {
+      if (kb == (top >> 4)) issue(std::integral_constant<int, kb>{}, std::integral_constant<int, buf>{});
+      if (16 * kb <= top) {
+        if constexpr (kb > 0) issue(std::integral_constant<int, kb - 1>{}, std::integral_constant<int, buf ^ 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<16>([&](auto jc) {
+          constexpr int j = 15 - decltype(jc)::value;
+          const int k = 16 * kb + j;
+          if (k <= top) {  // uniform; only the last block can be short
+            const float xk = __builtin_bit_cast(
+                float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z[Q]), k & 63));
+            static_for<Q + 1>([&](auto qc) {
+              constexpr int q = decltype(qc)::value;
+              z[q] = fmaf(-(col[buf][j][q] * rdl[q]), xk, z[q]);
+            });
+          }
+        });
+      }
+    }
+  });
+  static_for<NQ>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    if (lane + 64 * q < f) x_global[lane + 64 * q] = z[q];
+  });
+}
+
 // Does wave W need the eliminated panel row at feature block b while block row Ip is being
 // eliminated?  Yes if one of its live tiles (I >= Ip) has b as its row or column block; wave 0
 // additionally finalises the panel rows (all live blocks).
@@ -865,6 +936,10 @@ __device__ __forceinline__ void lu_solve_mfma(f32x4 (&acc)[Geo<NB>::TPW], float*
     }
   });
   float* ctab = rdiag + ((f + 3) & ~3);  // 2 x 16 floats, 16-byte aligned
+  float* zpad = ctab + 32;               // 16 zeros (back substitution: rows outside a pivot block read these)
+  if constexpr (W == 0) {
+    if (lane < 16) zpad[lane] = 0.f;
+  }
   float fin[NB];  // wave 0: eliminated rows of the previous panel at this lane's (row kk, columns 16 b + c)
   int fin_p0 = -1;
   auto write_fin = [&]() {  // rows fin_p0 + kk, blocks from the panel's own block row on
@@ -874,7 +949,10 @@ __device__ __forceinline__ void lu_solve_mfma(f32x4 (&acc)[Geo<NB>::TPW], float*
         const int b0 = fin_p0 >> 4;
         static_for<NB>([&](auto bc) {
           constexpr int b = decltype(bc)::value;
-          if (b >= b0 && (b < NB - 1 || 16 * b + c <= f)) w[16 * b] = fin[b];
+          // inside the row's own block the entries at or left of the diagonal are dead: store zeros
+          // there, so that the back substitution needs no triangle mask
+          const float v = (b > b0 || c > ((fin_p0 + kk) & 15)) ? fin[b] : 0.f;
+          if (b >= b0 && (b < NB - 1 || 16 * b + c <= f)) w[16 * b] = v;
         });
       }
     }
@@ -1016,7 +1094,7 @@ __device__ __forceinline__ void lu_solve_mfma(f32x4 (&acc)[Geo<NB>::TPW], float*
   write_fin();
   __syncthreads();
 #if !(CUMF_VARIANT_A & 8)
-  if constexpr (W == 0) back_substitute_fast<NB, (16 * NB + 63) / 64>(U, f, rdiag, x_global, lane);
+  if constexpr (W == 0) back_substitute_zeroed<NB, (16 * NB + 63) / 64>(U, f, rdiag, zpad, x_global, lane);
 #endif
 }
 
