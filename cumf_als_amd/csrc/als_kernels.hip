@@ -608,217 +608,16 @@ __device__ __forceinline__ void lu_solve_lds(float* __restrict__ G, int ldg, int
   if (tid < 64) back_substitute_lds<false, 4>(G, ldg, f, nullptr, x_global, tid);
 }
 
-// Back substitution of the register LU, U x = y with the reciprocals of the diagonal in rdiag
-// (wave 0).  The recurrence is a chain of f dependent steps, so everything that does not depend
-// on the running vector is moved off it: row i is pre-scaled by 1/u_ii (z_i = y_i / u_ii,
-// v_ik = u_ik / u_ii: unit diagonal, x_k = z_k needs no multiply), the column of step k is
-// fetched (kBackRing - 1) x kBackDepth steps ahead, masked (rows >= k -> 0) and scaled when it arrives, and the
-// pivots of rows 64.. and 0..63 get their own passes so the readlane register is static.  What
-// is left on the chain per step is one v_readlane and one v_fma.
-constexpr int kBackDepth = 4;
-#ifndef CUMF_BACK_RING
-#define CUMF_BACK_RING 2
-#endif
-constexpr int kBackRing = CUMF_BACK_RING;  // groups of columns in flight
-template <int NB, int NQ>
-__device__ __forceinline__ void back_substitute_fast(const float* __restrict__ U, int f,
-                                                     const float* __restrict__ rdiag,
-                                                     float* __restrict__ x_global, int lane) {
-  float z[NQ], rdl[NQ];
-  const float* rowp[NQ];
-  static_for<NQ>([&](auto qc) {
-    constexpr int q = decltype(qc)::value;
-    const int i = lane + 64 * q;
-    const int ic = i < f ? i : f - 1;
-    rowp[q] = U + lu_row_off<NB>(ic);
-    rdl[q] = i < f ? rdiag[ic] : 0.f;
-    z[q] = rowp[q][f] * rdl[q];
-  });
-  static_for<NQ>([&](auto pc) {
-    constexpr int Q = NQ - 1 - decltype(pc)::value;  // pivots 64Q .. 64Q+63 live in z[Q]
-    const int klo = 64 * Q;
-    const int top = (f - 1 < klo + 63) ? f - 1 : klo + 63;
-    if (top >= klo) {
-      // whole rounds of kBackRing groups x kBackDepth steps, no guards in the loop (a guard is a
-      // branch, and branches make the compiler wait for every outstanding LDS read): the steps
-      // above `top` that round the count up are no-ops (their column is masked to 0).  While one
-      // group of columns is consumed the others are in flight; the sched_barriers keep the
-      // compiler from sinking the reads next to their use.
-      constexpr int DR = kBackRing * kBackDepth;
-      const int khi = klo + ((top - klo + DR) / DR) * DR - 1;
-      float c[kBackRing][kBackDepth][Q + 1];
-      auto issue = [&](auto hc, int kfirst) {  // columns kfirst, kfirst-1, ... into group h
-        constexpr int h = decltype(hc)::value;
-        static_for<kBackDepth>([&](auto jc) {
-          constexpr int j = decltype(jc)::value;
-          int kc = kfirst - j > 0 ? kfirst - j : 0;
-          kc = kc <= top ? kc : top;
-          static_for<Q + 1>([&](auto qc) { c[h][j][decltype(qc)::value] = rowp[decltype(qc)::value][kc]; });
-        });
-      };
-      auto consume = [&](auto hc, int kfirst) {
-        constexpr int h = decltype(hc)::value;
-        static_for<kBackDepth>([&](auto jc) {
-          constexpr int j = decltype(jc)::value;
-          const int kk = kfirst - j;
-          const int lim = kk <= top ? kk : 0;  // rows below the pivot take part; none for a padding step
-          float v[Q + 1];
-          static_for<Q + 1>([&](auto qc) {
-            constexpr int q = decltype(qc)::value;
-            v[q] = (lane + 64 * q < lim) ? c[h][j][q] * rdl[q] : 0.f;
-          });
-          const float xk = __builtin_bit_cast(
-              float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z[Q]), kk & 63));
-          static_for<Q + 1>([&](auto qc) {
-            constexpr int q = decltype(qc)::value;
-            z[q] = fmaf(-v[q], xk, z[q]);
-          });
-        });
-      };
-      static_for<kBackRing>([&](auto gc) { issue(gc, khi - decltype(gc)::value * kBackDepth); });
-      __builtin_amdgcn_sched_barrier(0);
-      for (int k = khi; k >= klo; k -= DR) {
-        static_for<kBackRing>([&](auto gc) {
-          constexpr int g = decltype(gc)::value;
-          consume(gc, k - g * kBackDepth);
-          issue(gc, k - DR - g * kBackDepth);
-          __builtin_amdgcn_sched_barrier(0);
-        });
-      }
-    }
-  });
-  static_for<NQ>([&](auto qc) {
-    constexpr int q = decltype(qc)::value;
-    if (lane + 64 * q < f) x_global[lane + 64 * q] = z[q];
-  });
-}
-
-// Register-resident symmetric elimination (the fast LU path, f <= 200).
-// The upper triangle of [A | b] is spread over the 16 x 16 thread grid, element (i, j) in
-// thread (i & 15, j & 15), register block (i >> 4, j >> 4); `load(bi, bj)` fetches this
-// thread's element of block (bi, bj) (from the accumulator tiles parked in LDS, or from
-// global memory).  Per pivot k:
-//   1. the thread row owning row k publishes it (as it stands, i.e. updated by all earlier
-//      pivots) to the packed row store U (lu_row_off); the thread holding u_kk computes
-//      1 / u_kk meanwhile and publishes that too, so the reciprocal is off the readers'
-//      critical path; ONE barrier;
-//   2. every thread reads row k at its own row / column positions and applies
-//      a_ij -= (u_ki / u_kk) * u_kj  to its registers (i > k).
-// This is Gaussian elimination without pivoting restricted to the upper triangle (U = D L^T of
-// A = L U).  Tried and measured slower or equal (tools/lu_variants.sh): panels of 2 or 4
-// pivots per barrier with a redundant in-register panel elimination (half / quarter the
-// barriers, same LDS reads: equal at M = 2, spills at M = 4), a rolled pivot loop (+5 %).
-// U may alias the memory `load` reads from: all loads complete before the first publish.
-template <int NB, typename Load>
-__device__ __forceinline__ void lu_solve_reg(Load load, float* __restrict__ U, int f, float* __restrict__ rdiag,
-                                             float* __restrict__ x_global, int tid) {
-  const int ti = tid >> 4, tj = tid & 15;
-  float a[NB][NB];
-  static_for<NB>([&](auto bic) {
-    constexpr int bi = decltype(bic)::value;
-    static_for<NB>([&](auto bjc) {
-      constexpr int bj = decltype(bjc)::value;
-      if constexpr (bj >= bi) a[bi][bj] = load(bic, bjc, ti, tj);
-    });
-  });
-  __syncthreads();
-  // Rows >= f and columns > f of the register image are padding: never published, never read
-  // back, so updates run on them unmasked (whatever lands there is dead).  Reads of padding
-  // positions stay inside the row store and only feed dead registers.
-  const bool last_col_ok = 16 * (NB - 1) + tj <= f;
-  static_for<NB>([&](auto kbc) {
-    constexpr int kb = decltype(kbc)::value;
-    constexpr int pitch = lu_row_pitch<NB>(kb);
-    float* blk = U + lu_block_off<NB>(kb) - 16 * kb;  // element (16 kb, 0) of this block row
-    for (int kk = 0; kk < 16; ++kk) {
-      const int k = 16 * kb + kk;
-      if (k >= f) break;
-#if CUMF_VARIANT_A & 32
-      if (k >= 0) break;
-#endif
-      float* urow = blk + kk * pitch;
-      if (ti == kk) {
-        float* w = urow + tj;
-        static_for<NB>([&](auto bjc) {
-          constexpr int bj = decltype(bjc)::value;
-          if constexpr (bj >= kb && bj < NB - 1) w[16 * bj] = a[kb][bj];
-          if constexpr (bj >= kb && bj == NB - 1) {
-            if (last_col_ok) w[16 * bj] = a[kb][bj];
-          }
-        });
-        if (tj == kk) {
-          const float piv = a[kb][kb];
-          const float t = __builtin_amdgcn_rcpf(piv);
-          rdiag[k] = fmaf(fmaf(-piv, t, 1.0f), t, t);  // one Newton step: 1/pivot to ~1 ulp
-        }
-      }
-#if !(CUMF_VARIANT_A & 4)
-      __syncthreads();
-#endif
-      float ui[NB], uj[NB];
-      const float nrp = -rdiag[k];
-      static_for<NB>([&](auto bc) {
-        constexpr int b = decltype(bc)::value;
-        if constexpr (b >= kb) {
-          uj[b] = urow[16 * b + tj];
-#if CUMF_VARIANT_A & 1
-          ui[b] = uj[b];
-#else
-          ui[b] = urow[16 * b + ti];
-#endif
-        }
-      });
-      static_for<NB>([&](auto bc) {
-        constexpr int b = decltype(bc)::value;
-        if constexpr (b > kb) ui[b] = ui[b] * nrp;
-        if constexpr (b == kb) ui[b] = (ti > kk) ? ui[b] * nrp : 0.f;
-      });
-      static_for<NB>([&](auto bic) {
-        constexpr int bi = decltype(bic)::value;
-        static_for<NB>([&](auto bjc) {
-          constexpr int bj = decltype(bjc)::value;
-#if CUMF_VARIANT_A & 2
-          if constexpr (bi >= kb && bj == bi) a[bi][bj] = fmaf(ui[bi], uj[bj], a[bi][bj]);
-#else
-          if constexpr (bi >= kb && bj >= bi) a[bi][bj] = fmaf(ui[bi], uj[bj], a[bi][bj]);
-#endif
-        });
-      });
-    }
-  });
-  __syncthreads();
-#if !(CUMF_VARIANT_A & 8)
-  if (tid < 64) back_substitute_fast<NB, (16 * NB + 63) / 64>(U, f, rdiag, x_global, tid);
-#endif
-}
-
-// ----------------------------------------------------------------------------------
-// LU directly on the MFMA accumulators (the fused kernels' LU path).
-//
-// After the Gram pass wave W holds tiles [W*TPW, (W+1)*TPW) of the upper triangle of [A | b] in
-// the 16x16x4 C/D layout (lane (kk, c) = (l >> 4, l & 15), register r: element
-// (16 I + 4 kk + r, 16 J + c)).  The elimination keeps them there and applies FOUR pivots per
-// step as one rank-4 MFMA per tile:
-//   1. the lanes holding the panel rows p0 .. p0+3 (block row Ip, lane group kk = q) publish them
-//      raw -- updated by all earlier panels -- into the packed row store U; ONE barrier;
-//   2. every wave reads the 4x4 pivot block and eliminates it redundantly (multipliers m_kq,
-//      reciprocals 1/u_kk), then per live feature block b >= Ip reads the four raw rows at its
-//      column and forms the eliminated row of ITS lane group, ub[b] = U'[kk][16 b + c];
-//   3. A operand of tile (I, J) = -ub[I] / u_kk masked to rows below the pivot (by symmetry
-//      a_i,pk = u'_k,i), B operand = ub[J]:  acc -= L21 * U12  in one v_mfma_f32_16x16x4_f32;
-//   4. wave 0 stores the eliminated rows (final rows of U) into the row store after the NEXT
-//      barrier, when nobody reads the raw copies any more.
-// Compared with lu_solve_reg: no hand-over of the tiles through LDS, a quarter of the barriers,
-// the trailing update on the otherwise idle matrix pipe.  Unpivoted Gaussian elimination as
-// before (the content of getrfBatched(Pivot = NULL) + getrs); operation order differs from the
-// oracle's, parity is by tolerance (tests/test_gpu_parity.py).
-// ----------------------------------------------------------------------------------
-// Back substitution of the accumulator LU (one wave).  Same recurrence as back_substitute_fast, but
-// organised by 16-pivot blocks on a row store whose entries at or left of the diagonal inside the
-// diagonal blocks are zero (lu_solve_mfma's write_fin): the lanes of the pivot block then need no
-// triangle mask, the lanes of later blocks are pointed at 16 zeros (zpad) once per block, and the
-// 16 columns of a block are read with immediate offsets from one base per lane.  Per step that
-// leaves v_readlane, one packed multiply (the 1/u_ii scaling) and one packed FMA.
+// Back substitution of the fast LU paths, U x = y with y = column f of the packed row store and the
+// reciprocals of the diagonal in rdiag (one wave; lane i holds rows i, i + 64, ...).  The
+// recurrence is a chain of f dependent steps, so everything that does not depend on the running
+// vector is moved off it: row i is scaled by 1/u_ii (z_i = y_i / u_ii, v_ik = u_ik / u_ii: unit
+// diagonal, x_k = z_k needs no multiply), and the work is organised by 16-pivot blocks on a row
+// store whose entries at or left of the diagonal inside the diagonal blocks are zero (the
+// publishers write zeros there): the lanes of the pivot block then need no triangle mask, the
+// lanes of later blocks are pointed at 16 zeros (zpad) once per block, the 16 columns of a block
+// are read with immediate offsets from one base per lane, one block ahead of their use.  Per
+// step that leaves v_readlane, one packed multiply (the 1/u_ii scaling) and one packed FMA.
 template <int NB, int NQ>
 __device__ __forceinline__ void back_substitute_zeroed(const float* __restrict__ U, int f,
                                                        const float* __restrict__ rdiag,
@@ -884,6 +683,131 @@ __device__ __forceinline__ void back_substitute_zeroed(const float* __restrict__
   });
 }
 
+// Register-resident symmetric elimination (the fast LU path, f <= 200).
+// The upper triangle of [A | b] is spread over the 16 x 16 thread grid, element (i, j) in
+// thread (i & 15, j & 15), register block (i >> 4, j >> 4); `load(bi, bj)` fetches this
+// thread's element of block (bi, bj) (from the accumulator tiles parked in LDS, or from
+// global memory).  Per pivot k:
+//   1. the thread row owning row k publishes it (as it stands, i.e. updated by all earlier
+//      pivots) to the packed row store U (lu_row_off); the thread holding u_kk computes
+//      1 / u_kk meanwhile and publishes that too, so the reciprocal is off the readers'
+//      critical path; ONE barrier;
+//   2. every thread reads row k at its own row / column positions and applies
+//      a_ij -= (u_ki / u_kk) * u_kj  to its registers (i > k).
+// This is Gaussian elimination without pivoting restricted to the upper triangle (U = D L^T of
+// A = L U).  Tried and measured slower or equal (tools/lu_variants.sh): panels of 2 or 4
+// pivots per barrier with a redundant in-register panel elimination (half / quarter the
+// barriers, same LDS reads: equal at M = 2, spills at M = 4), a rolled pivot loop (+5 %).
+// U may alias the memory `load` reads from: all loads complete before the first publish.
+template <int NB, typename Load>
+__device__ __forceinline__ void lu_solve_reg(Load load, float* __restrict__ U, int f, float* __restrict__ rdiag,
+                                             float* __restrict__ x_global, int tid) {
+  const int ti = tid >> 4, tj = tid & 15;
+  float* zpad = rdiag + ((f + 3) & ~3) + 32;  // 16 zeros for back_substitute_zeroed (same place as in lu_solve_mfma)
+  if (tid < 16) zpad[tid] = 0.f;
+  float a[NB][NB];
+  static_for<NB>([&](auto bic) {
+    constexpr int bi = decltype(bic)::value;
+    static_for<NB>([&](auto bjc) {
+      constexpr int bj = decltype(bjc)::value;
+      if constexpr (bj >= bi) a[bi][bj] = load(bic, bjc, ti, tj);
+    });
+  });
+  __syncthreads();
+  // Rows >= f and columns > f of the register image are padding: never published, never read
+  // back, so updates run on them unmasked (whatever lands there is dead).  Reads of padding
+  // positions stay inside the row store and only feed dead registers.
+  const bool last_col_ok = 16 * (NB - 1) + tj <= f;
+  static_for<NB>([&](auto kbc) {
+    constexpr int kb = decltype(kbc)::value;
+    constexpr int pitch = lu_row_pitch<NB>(kb);
+    float* blk = U + lu_block_off<NB>(kb) - 16 * kb;  // element (16 kb, 0) of this block row
+    for (int kk = 0; kk < 16; ++kk) {
+      const int k = 16 * kb + kk;
+      if (k >= f) break;
+#if CUMF_VARIANT_A & 32
+      if (k >= 0) break;
+#endif
+      float* urow = blk + kk * pitch;
+      if (ti == kk) {
+        float* w = urow + tj;
+        static_for<NB>([&](auto bjc) {
+          constexpr int bj = decltype(bjc)::value;
+          // entries at or left of the diagonal inside the row's own block are dead for the
+          // elimination: publish zeros there, the back substitution then needs no triangle mask
+          const float v = (bj > kb || tj > kk) ? a[kb][bj] : 0.f;
+          if constexpr (bj >= kb && bj < NB - 1) w[16 * bj] = v;
+          if constexpr (bj >= kb && bj == NB - 1) {
+            if (last_col_ok) w[16 * bj] = v;
+          }
+        });
+        if (tj == kk) {
+          const float piv = a[kb][kb];
+          const float t = __builtin_amdgcn_rcpf(piv);
+          rdiag[k] = fmaf(fmaf(-piv, t, 1.0f), t, t);  // one Newton step: 1/pivot to ~1 ulp
+        }
+      }
+#if !(CUMF_VARIANT_A & 4)
+      __syncthreads();
+#endif
+      float ui[NB], uj[NB];
+      const float nrp = -rdiag[k];
+      static_for<NB>([&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        if constexpr (b >= kb) {
+          uj[b] = urow[16 * b + tj];
+#if CUMF_VARIANT_A & 1
+          ui[b] = uj[b];
+#else
+          ui[b] = urow[16 * b + ti];
+#endif
+        }
+      });
+      static_for<NB>([&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        if constexpr (b > kb) ui[b] = ui[b] * nrp;
+        if constexpr (b == kb) ui[b] = (ti > kk) ? ui[b] * nrp : 0.f;
+      });
+      static_for<NB>([&](auto bic) {
+        constexpr int bi = decltype(bic)::value;
+        static_for<NB>([&](auto bjc) {
+          constexpr int bj = decltype(bjc)::value;
+#if CUMF_VARIANT_A & 2
+          if constexpr (bi >= kb && bj == bi) a[bi][bj] = fmaf(ui[bi], uj[bj], a[bi][bj]);
+#else
+          if constexpr (bi >= kb && bj >= bi) a[bi][bj] = fmaf(ui[bi], uj[bj], a[bi][bj]);
+#endif
+        });
+      });
+    }
+  });
+  __syncthreads();
+#if !(CUMF_VARIANT_A & 8)
+  if (tid < 64) back_substitute_zeroed<NB, (16 * NB + 63) / 64>(U, f, rdiag, zpad, x_global, tid);
+#endif
+}
+
+// ----------------------------------------------------------------------------------
+// LU directly on the MFMA accumulators (the fused kernels' LU path).
+//
+// After the Gram pass wave W holds tiles [W*TPW, (W+1)*TPW) of the upper triangle of [A | b] in
+// the 16x16x4 C/D layout (lane (kk, c) = (l >> 4, l & 15), register r: element
+// (16 I + 4 kk + r, 16 J + c)).  The elimination keeps them there and applies FOUR pivots per
+// step as one rank-4 MFMA per tile:
+//   1. the lanes holding the panel rows p0 .. p0+3 (block row Ip, lane group kk = q) publish them
+//      raw -- updated by all earlier panels -- into the packed row store U; ONE barrier;
+//   2. every wave reads the 4x4 pivot block and eliminates it redundantly (multipliers m_kq,
+//      reciprocals 1/u_kk), then per live feature block b >= Ip reads the four raw rows at its
+//      column and forms the eliminated row of ITS lane group, ub[b] = U'[kk][16 b + c];
+//   3. A operand of tile (I, J) = -ub[I] / u_kk masked to rows below the pivot (by symmetry
+//      a_i,pk = u'_k,i), B operand = ub[J]:  acc -= L21 * U12  in one v_mfma_f32_16x16x4_f32;
+//   4. wave 0 stores the eliminated rows (final rows of U) into the row store after the NEXT
+//      barrier, when nobody reads the raw copies any more.
+// Compared with lu_solve_reg: no hand-over of the tiles through LDS, a quarter of the barriers,
+// the trailing update on the otherwise idle matrix pipe.  Unpivoted Gaussian elimination as
+// before (the content of getrfBatched(Pivot = NULL) + getrs); operation order differs from the
+// oracle's, parity is by tolerance (tests/test_gpu_parity.py).
+// ----------------------------------------------------------------------------------
 // Does wave W need the eliminated panel row at feature block b while block row Ip is being
 // eliminated?  Yes if one of its live tiles (I >= Ip) has b as its row or column block; wave 0
 // additionally finalises the panel rows (all live blocks).
