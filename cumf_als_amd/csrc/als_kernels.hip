@@ -841,6 +841,17 @@ __host__ __device__ constexpr int lu_diag_owner(int Ip) {
   return 0;
 }
 
+// Accumulator slot of the diagonal tile (Ip, Ip) in role W.
+template <int NB>
+__host__ __device__ constexpr int lu_diag_slot(int W, int Ip) {
+  constexpr int NT = Geo<NB>::NT, TPW = Geo<NB>::TPW;
+  for (int s = 0; s < TPW; ++s) {
+    const int t = Geo<NB>::tile(W, s);
+    if (t < NT && tile_I<NB>(t) == Ip && tile_J<NB>(t) == Ip) return s;
+  }
+  return 0;
+}
+
 template <int NB, int W>
 __device__ __forceinline__ void lu_solve_mfma(f32x4 (&acc)[Geo<NB>::TPW], float* __restrict__ U,
                                               float* __restrict__ rdiag, int f, float reg,
@@ -916,15 +927,19 @@ __device__ __forceinline__ void lu_solve_mfma(f32x4 (&acc)[Geo<NB>::TPW], float*
       float c0 = 0.f, c1 = 0.f, c2 = 0.f, nrp = 0.f;
       constexpr int OWNER = lu_diag_owner<NB>(Ip);
       if constexpr (W == OWNER) {
-        const float* o0 = U + lu_row_off<NB>(p0);
-        const float* o1 = U + lu_row_off<NB>(p0 + 1 < f ? p0 + 1 : p0);
-        const float* o2 = U + lu_row_off<NB>(p0 + 2 < f ? p0 + 2 : p0);
-        const float* o3 = U + lu_row_off<NB>(p0 + 3 < f ? p0 + 3 : p0);
+        // the 4 x 4 pivot block sits in this role's diagonal tile: rows = registers 0..3 of lane group q,
+        // columns = lanes 4q .. 4q+3 of that group: fetch it with v_readlane, no LDS round trip
+        constexpr int SD = lu_diag_slot<NB>(OWNER, Ip);
+        const int l0 = 20 * q;  // lane of (lane group q, column 4 q)
+        auto rl = [&](float v, int l) {
+          return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+        };
         const bool v1 = p0 + 1 < f, v2 = p0 + 2 < f, v3 = p0 + 3 < f;
-        float P00 = o0[p0], P01 = o0[p0 + 1], P02 = o0[p0 + 2], P03 = o0[p0 + 3];
-        float P11 = o1[p0 + 1], P12 = o1[p0 + 2], P13 = o1[p0 + 3];
-        float P22 = o2[p0 + 2], P23 = o2[p0 + 3];
-        float P33 = o3[p0 + 3];
+        float P00 = rl(acc[SD][0], l0), P01 = rl(acc[SD][0], l0 + 1), P02 = rl(acc[SD][0], l0 + 2),
+              P03 = rl(acc[SD][0], l0 + 3);
+        float P11 = rl(acc[SD][1], l0 + 1), P12 = rl(acc[SD][1], l0 + 2), P13 = rl(acc[SD][1], l0 + 3);
+        float P22 = rl(acc[SD][2], l0 + 2), P23 = rl(acc[SD][2], l0 + 3);
+        float P33 = rl(acc[SD][3], l0 + 3);
         // v_rcp_f32 is accurate to 1 ulp; the four reciprocals are a dependent chain, so no Newton step
         auto recip = [](float d) { return __builtin_amdgcn_rcpf(d); };
         const float rp0 = recip(P00);
