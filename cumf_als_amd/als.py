@@ -217,6 +217,20 @@ def sse(val, row, col, thetaT, XT, count: int | None = None, surpass_nan: bool =
     return out
 
 
+GRAM_AUTO, GRAM_EXACT = 0, 1
+
+
+def set_gram_mode(mode) -> None:
+    """Arithmetic of the Gram pass (cumf_set_gram_mode): "auto"/"split" = fp32 via exact bf16x3
+    splits on the bf16 matrix pipe where available, "exact" = fp32 MFMA (fmaf-chain bits)."""
+    m = {"auto": GRAM_AUTO, "split": GRAM_AUTO, "exact": GRAM_EXACT}.get(mode, mode)
+    _libmod.check(_libmod.load().cumf_set_gram_mode(int(m)), "cumf_set_gram_mode")
+
+
+def get_gram_mode() -> str:
+    return "exact" if _libmod.load().cumf_get_gram_mode() == GRAM_EXACT else "auto"
+
+
 def set_kernel_timing(enable: bool) -> None:
     _libmod.check(_libmod.load().cumf_set_kernel_timing(int(bool(enable))), "cumf_set_kernel_timing")
 

@@ -13,6 +13,7 @@ constexpr int kStage = 32;      // gathered factor rows per LDS stage
 constexpr int kVecLd = 128;     // pitch of the CG vectors in LDS (fused solve needs f <= 128)
 constexpr int kMaxFusedNB = 9;  // f <= 128  ->  NB = f / 16 + 1 <= 9
 constexpr int kMaxF = 207;      // NB <= 13
+constexpr int kMaxWaveNB = 7;   // wave-per-item kernels (als_wave.hip): f <= 111; register budget of one wave
 
 enum { kModeCG = 0, kModeLU = 1, kModeMaterialize = 2, kModeLUExact = 3 };
 
@@ -72,6 +73,15 @@ struct KernelArgs {
 hipError_t launch_half_iteration(const KernelArgs& a, int mode, long n_items, long n_mrows, hipStream_t stream);
 hipError_t launch_solve_batched(const float* A, const float* b, float* x, long batch, int f, int mode, int cg_iters,
                                 hipStream_t stream);
+// Gram arithmetic of the fused / materialising passes.
+//   kGramSplit: fp32 values split exactly into three bf16 terms, six bf16 MFMA products per fp32
+//               product, fp32 accumulation (als_wave.hip; fp32-class error, not bit-identical to a
+//               fmaf chain); used where the wave-per-item kernels exist (LU and materialise, f <= 111),
+//   kGramExact: v_mfma_f32_16x16x4_f32, bit-identical to the reference thread's fmaf chain.
+enum { kGramAuto = 0, kGramExact = 1 };
+void set_gram_mode(int mode);
+int gram_mode();
+bool wave_path_available(int f, int mode);
 void set_kernel_timing(bool on);
 hipError_t last_kernel_ms(float* item_ms, float* reduce_ms);
 hipError_t launch_sse(const float* val, const int* row, const int* col, const float* thetaT, const float* XT,

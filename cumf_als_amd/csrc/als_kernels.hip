@@ -29,11 +29,10 @@
 #include <utility>
 
 #include "als_internal.h"
+#include "als_device.h"
 
 namespace cumf {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // The file is compiled once per NB (Makefile: -DCUMF_NB_SLICE=1..13, the kernels of that
 // feature-block count) plus once with -DCUMF_NB_SLICE=0 (dispatch, NB-independent kernels,
@@ -89,42 +88,6 @@ struct Geo {
     return (kRoundRobinTiles && NB >= 7) ? W + 4 * s : W * TPW + s;
   }
 };
-
-// Row-major enumeration of the upper triangle: t -> (I, J), I <= J < NB.
-template <int NB>
-__host__ __device__ constexpr int tile_I(int t) {
-  int I = 0, rem = t;
-  while (rem >= NB - I) {
-    rem -= NB - I;
-    ++I;
-  }
-  return I;
-}
-template <int NB>
-__host__ __device__ constexpr int tile_J(int t) {
-  int I = 0, rem = t;
-  while (rem >= NB - I) {
-    rem -= NB - I;
-    ++I;
-  }
-  return I + rem;
-}
-
-// Compile-time loop: body(std::integral_constant<int, i>) for i in [0, N).
-template <typename F, int... Is>
-__device__ __forceinline__ void static_for_impl(F&& body, std::integer_sequence<int, Is...>) {
-  (body(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& body) {
-  static_for_impl(body, std::make_integer_sequence<int, N>{});
-}
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
 
 // ----------------------------------------------------------------------------------
 // Global -> register -> LDS staging of kStage gathered factor rows.
@@ -302,26 +265,6 @@ __device__ __forceinline__ void mma_stage(const float* __restrict__ stage, f32x4
   if (g < ngroups) mma_group<NB, W>(blk_a, acc);
 }
 
-// Packed row store of the register LU: block row kb (rows 16 kb .. 16 kb + 15) keeps columns
-// 16 kb .. 16 NB - 1 only, at an odd pitch (the back substitution walks columns).  For NB = 7
-// that is 7 280 floats instead of the 10 100 of a full f x (f + 1) matrix, which is what lets
-// a fifth workgroup share the CU.
-template <int NB>
-__host__ __device__ constexpr int lu_row_pitch(int kb) { return 16 * (NB - kb) + 1; }
-template <int NB>
-__host__ __device__ constexpr int lu_block_off(int kb) { return 256 * (kb * NB - kb * (kb - 1) / 2) + 16 * kb; }
-// offset of the (virtual) element (k, 0); valid for columns j >= 16 * (k >> 4)
-template <int NB>
-__device__ __forceinline__ int lu_row_off(int k) {
-  const int kb = k >> 4, kk = k & 15;
-  return 256 * (kb * NB - ((kb * (kb - 1)) >> 1)) + kk * (16 * (NB - kb) + 1);
-}
-template <int NB>
-__host__ __device__ constexpr int tile_of(int I, int J) { return I * NB - I * (I - 1) / 2 + (J - I); }
-// row m of a 16 x 16 tile parked in LDS sits at slot 4 * (m & 3) + (m >> 2): the accumulator
-// store (lane group kk writes rows 4 kk + r) then spreads over all 32 banks.
-__device__ __forceinline__ int tiled_row(int m) { return 4 * (m & 3) + (m >> 2); }
-
 // Accumulator tiles -> LDS, tile-major ([tile][16][16], rows permuted by tiled_row): the
 // hand-over to lu_solve_reg, whose threads pick their elements up with TileLoad.
 template <int NB, int W>
@@ -429,23 +372,6 @@ __device__ __forceinline__ void partial_accumulate(f32x4 (&acc)[Geo<NB>::TPW], c
 // In-LDS solvers.  G is f x ldg (ldg = solve_ldg(f): f + 1 rounded up to 4, so rows
 // are 16-byte aligned), column f holds b.  256 threads.
 // ----------------------------------------------------------------------------------
-
-// Deterministic wave64 sum on the DPP cross-lane network (no LDS traffic): xor-1, xor-2,
-// half-mirror, mirror inside each row of 16, then row_bcast15 / row_bcast31 across rows;
-// lane 63 ends with the total, returned wave-uniform.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_term(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
-}
-__device__ __forceinline__ float wave_sum_uniform(float v) {
-  v += dpp_term<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
-  v += dpp_term<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
-  v += dpp_term<0x141, 0xf>(v);  // row_half_mirror
-  v += dpp_term<0x140, 0xf>(v);  // row_mirror  -> every lane holds its row's sum
-  v += dpp_term<0x142, 0xa>(v);  // row_bcast15 -> rows 1,3 += rows 0,2
-  v += dpp_term<0x143, 0xc>(v);  // row_bcast31 -> rows 2,3 += row 1
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
 
 // Conjugate gradient exactly as cg.cu:36-231: warm start, r = b - A x, <= cg_iters
 // iterations, stop when ||r||^2 < 1e-4 (CG_ERROR, cg.cu:31,195; the float is compared
@@ -606,81 +532,6 @@ __device__ __forceinline__ void lu_solve_lds(float* __restrict__ G, int ldg, int
     __syncthreads();
   }
   if (tid < 64) back_substitute_lds<false, 4>(G, ldg, f, nullptr, x_global, tid);
-}
-
-// Back substitution of the fast LU paths, U x = y with y = column f of the packed row store and the
-// reciprocals of the diagonal in rdiag (one wave; lane i holds rows i, i + 64, ...).  The
-// recurrence is a chain of f dependent steps, so everything that does not depend on the running
-// vector is moved off it: row i is scaled by 1/u_ii (z_i = y_i / u_ii, v_ik = u_ik / u_ii: unit
-// diagonal, x_k = z_k needs no multiply), and the work is organised by 16-pivot blocks on a row
-// store whose entries at or left of the diagonal inside the diagonal blocks are zero (the
-// publishers write zeros there): the lanes of the pivot block then need no triangle mask, the
-// lanes of later blocks are pointed at 16 zeros (zpad) once per block, the 16 columns of a block
-// are read with immediate offsets from one base per lane, one block ahead of their use.  Per
-// step that leaves v_readlane, one packed multiply (the 1/u_ii scaling) and one packed FMA.
-template <int NB, int NQ>
-__device__ __forceinline__ void back_substitute_zeroed(const float* __restrict__ U, int f,
-                                                       const float* __restrict__ rdiag,
-                                                       const float* __restrict__ zpad,
-                                                       float* __restrict__ x_global, int lane) {
-  float z[NQ], rdl[NQ];
-  const float* rowp[NQ];
-  int ib[NQ];  // block of this lane's row
-  static_for<NQ>([&](auto qc) {
-    constexpr int q = decltype(qc)::value;
-    const int i = lane + 64 * q;
-    const int ic = i < f ? i : f - 1;
-    ib[q] = i < f ? (i >> 4) : 1 << 20;  // rows past f never take part
-    rowp[q] = U + lu_row_off<NB>(ic);
-    rdl[q] = i < f ? rdiag[ic] : 0.f;
-    z[q] = rowp[q][f] * rdl[q];
-  });
-  const int top = f - 1;
-  constexpr int NBLK = NB;  // pivot blocks 0 .. (f-1)>>4 <= NB-1
-  // two column buffers: the 16 columns of the next block are in flight while this one is consumed
-  float col[2][16][NQ];
-  auto issue = [&](auto kbc, auto bufc) {
-    constexpr int kb = decltype(kbc)::value, buf = decltype(bufc)::value, Q = kb >> 2;
-    // per lane: the 16 entries of its row in the block's columns (zeros for rows of later blocks)
-    const float* base[Q + 1];
-    static_for<Q + 1>([&](auto qc) {
-      constexpr int q = decltype(qc)::value;
-      base[q] = (ib[q] > kb) ? zpad : rowp[q] + 16 * kb;
-    });
-    static_for<16>([&](auto jc) {  // issued in the order they are consumed (LDS returns in order)
-      constexpr int j = 15 - decltype(jc)::value;
-      static_for<Q + 1>([&](auto qc) { col[buf][j][decltype(qc)::value] = base[decltype(qc)::value][j]; });
-    });
-  };
-  static_for<NBLK>([&](auto bc) {
-    constexpr int n = decltype(bc)::value;
-    constexpr int kb = NBLK - 1 - n;
-    constexpr int buf = n & 1;
-    constexpr int Q = kb >> 2;  // pivots of this block live in z[Q]
-    if constexpr (Q < NQ) {
-      if (kb == (top >> 4)) issue(std::integral_constant<int, kb>{}, std::integral_constant<int, buf>{});
-      if (16 * kb <= top) {
-        if constexpr (kb > 0) issue(std::integral_constant<int, kb - 1>{}, std::integral_constant<int, buf ^ 1>{});
-        __builtin_amdgcn_sched_barrier(0);
-        static_for<16>([&](auto jc) {
-          constexpr int j = 15 - decltype(jc)::value;
-          const int k = 16 * kb + j;
-          if (k <= top) {  // uniform; only the last block can be short
-            const float xk = __builtin_bit_cast(
-                float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z[Q]), k & 63));
-            static_for<Q + 1>([&](auto qc) {
-              constexpr int q = decltype(qc)::value;
-              z[q] = fmaf(-(col[buf][j][q] * rdl[q]), xk, z[q]);
-            });
-          }
-        });
-      }
-    }
-  });
-  static_for<NQ>([&](auto qc) {
-    constexpr int q = decltype(qc)::value;
-    if (lane + 64 * q < f) x_global[lane + 64 * q] = z[q];
-  });
 }
 
 // Register-resident symmetric elimination (the fast LU path, f <= 200).
@@ -1538,6 +1389,21 @@ static hipError_t launch_solve_nb(const float* A, const float* b, float* x, long
   return hipGetLastError();
 }
 
+// reduce kernel of the chunked rows on its own (the items came from the wave-per-item kernel)
+template <int NB>
+static hipError_t launch_reduce_only(const KernelArgs& a, int mode, long n_mrows, hipStream_t stream) {
+  if (n_mrows <= 0) return hipSuccess;
+  if (mode == kModeMaterialize) {
+    hipLaunchKernelGGL((als_reduce_kernel<NB, kModeMaterialize>), dim3((unsigned)n_mrows), dim3(kThreads), 0, stream, a);
+  } else {
+    const size_t lds = lu_lds_floats(NB, a.f) * sizeof(float);
+    hipLaunchKernelGGL((als_reduce_kernel<NB, kModeLU>), dim3((unsigned)n_mrows), dim3(kThreads), lds, stream, a);
+  }
+  return hipGetLastError();
+}
+template <int NB>
+hipError_t slice_reduce_only(const KernelArgs& a, int mode, long n_mrows, hipStream_t stream);
+
 // Per-NB entry points (one translation unit each, see CUMF_NB_SLICE above).
 template <int NB>
 hipError_t slice_half_iteration(const KernelArgs& a, int mode, long n_items, long n_mrows, hipStream_t stream);
@@ -1550,7 +1416,9 @@ hipError_t slice_solve(const float* A, const float* b, float* x, long batch, int
   hipError_t slice_half_iteration<N>(const KernelArgs& a, int mode, long n_items, long n_mrows, hipStream_t stream); \
   template <>                                                                                                    \
   hipError_t slice_solve<N>(const float* A, const float* b, float* x, long batch, int f, int mode, int cg_iters, \
-                            hipStream_t stream);
+                            hipStream_t stream);                                                                 \
+  template <>                                                                                                    \
+  hipError_t slice_reduce_only<N>(const KernelArgs& a, int mode, long n_mrows, hipStream_t stream);
 #define CUMF_STUB_SLICE(N)                                                                                       \
   template <>                                                                                                    \
   hipError_t slice_half_iteration<N>(const KernelArgs&, int, long, long, hipStream_t) {                          \
@@ -1558,6 +1426,10 @@ hipError_t slice_solve(const float* A, const float* b, float* x, long batch, int
   }                                                                                                              \
   template <>                                                                                                    \
   hipError_t slice_solve<N>(const float*, const float*, float*, long, int, int, int, hipStream_t) {              \
+    return hipErrorInvalidValue;                                                                                 \
+  }                                                                                                              \
+  template <>                                                                                                    \
+  hipError_t slice_reduce_only<N>(const KernelArgs&, int, long, hipStream_t) {                                   \
     return hipErrorInvalidValue;                                                                                 \
   }
 #define CUMF_DEFINE_SLICE(N)                                                                                     \
@@ -1574,6 +1446,10 @@ hipError_t slice_solve(const float* A, const float* b, float* x, long batch, int
       return hipErrorInvalidValue;                                                                               \
     }                                                                                                            \
     return launch_solve_nb<N, kModeLU>(A, b, x, batch, f, cg_iters, stream);                                     \
+  }                                                                                                              \
+  template <>                                                                                                    \
+  hipError_t slice_reduce_only<N>(const KernelArgs& a, int mode, long n_mrows, hipStream_t stream) {             \
+    return launch_reduce_only<N>(a, mode, n_mrows, stream);                                                      \
   }
 
 CUMF_DECLARE_SLICE(1) CUMF_DECLARE_SLICE(2) CUMF_DECLARE_SLICE(3) CUMF_DECLARE_SLICE(4) CUMF_DECLARE_SLICE(5)
@@ -1648,7 +1524,49 @@ CUMF_STUB_SLICE(13)
 #if CUMF_SLICE_COMMON
 #define CUMF_NB_CASE(N, call) case N: return call;
 
+// wave-per-item kernels (als_wave.hip), one translation unit per NB
+template <int NB>
+hipError_t wave_item_launch(const KernelArgs& a, int mode, long n_items, hipStream_t stream);
+#define CUMF_DECLARE_WAVE(N) \
+  template <>                \
+  hipError_t wave_item_launch<N>(const KernelArgs& a, int mode, long n_items, hipStream_t stream);
+CUMF_DECLARE_WAVE(1) CUMF_DECLARE_WAVE(2) CUMF_DECLARE_WAVE(3) CUMF_DECLARE_WAVE(4) CUMF_DECLARE_WAVE(5)
+CUMF_DECLARE_WAVE(6) CUMF_DECLARE_WAVE(7)
+
+static int g_gram_mode = -1;
+void set_gram_mode(int mode) { g_gram_mode = mode == kGramExact ? kGramExact : kGramAuto; }
+int gram_mode() {
+  if (g_gram_mode < 0) {
+    const char* e = getenv("CUMF_ALS_GRAM");  // exact | split (default)
+    g_gram_mode = (e && (e[0] == 'e' || e[0] == 'E')) ? kGramExact : kGramAuto;
+  }
+  return g_gram_mode;
+}
+bool wave_path_available(int f, int mode) {
+  return gram_mode() != kGramExact && nb_for_f(f) <= kMaxWaveNB && (mode == kModeLU || mode == kModeMaterialize);
+}
+
 hipError_t launch_half_iteration(const KernelArgs& a, int mode, long n_items, long n_mrows, hipStream_t stream) {
+  if (wave_path_available(a.f, mode)) {
+    if (g_timing) (void)hipEventRecord(g_ev[0], stream);
+    g_timed_item = n_items > 0;
+    g_timed_reduce = n_mrows > 0;
+    hipError_t e = hipSuccess;
+    switch (nb_for_f(a.f)) {
+#define CUMF_WAVE(N)                                              \
+  case N:                                                         \
+    e = wave_item_launch<N>(a, mode, n_items, stream);            \
+    if (e != hipSuccess) return e;                                \
+    if (g_timing) (void)hipEventRecord(g_ev[1], stream);          \
+    e = slice_reduce_only<N>(a, mode, n_mrows, stream);           \
+    break;
+      CUMF_WAVE(1) CUMF_WAVE(2) CUMF_WAVE(3) CUMF_WAVE(4) CUMF_WAVE(5) CUMF_WAVE(6) CUMF_WAVE(7)
+#undef CUMF_WAVE
+      default: return hipErrorInvalidValue;
+    }
+    if (g_timing) (void)hipEventRecord(g_ev[2], stream);
+    return e;
+  }
 #define CUMF_HALF(N) CUMF_NB_CASE(N, slice_half_iteration<N>(a, mode, n_items, n_mrows, stream))
   switch (nb_for_f(a.f)) {
     CUMF_HALF(1) CUMF_HALF(2) CUMF_HALF(3) CUMF_HALF(4) CUMF_HALF(5) CUMF_HALF(6) CUMF_HALF(7)

@@ -276,6 +276,13 @@ extern "C" int cumf_sse(const float* val, const int* row, const int* col, const 
   return 0;
 }
 
+extern "C" int cumf_set_gram_mode(int mode) {
+  if (mode != CUMF_GRAM_AUTO && mode != CUMF_GRAM_EXACT) return (int)hipErrorInvalidValue;
+  set_gram_mode(mode);
+  return 0;
+}
+extern "C" int cumf_get_gram_mode(void) { return gram_mode(); }
+
 extern "C" int cumf_set_kernel_timing(int enable) {
   set_kernel_timing(enable != 0);
   return 0;

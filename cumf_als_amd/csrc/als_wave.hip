@@ -1,0 +1,543 @@
+// als_wave.hip -- wave-per-item ALS half-iteration kernels for gfx950 (f <= 128).
+//
+// Same job as als_item_kernel (als_kernels.hip) -- RHS + Gram + solve of one plan item,
+// replacing cusparseScsrmm2 + cublasSgeam (als.cu:750-757), get_hermitian100 /
+// get_hermitianT10 (als.cu:443-569 / 575-659) and the batched LU (als.cu:58-189) -- with a
+// different mapping onto the chip:
+//
+//   * ONE wave owns one item and all NB (NB + 1) / 2 upper-triangular 16 x 16 accumulator
+//     tiles of its system.  No workgroup barrier anywhere, no staging through LDS: every
+//     lane gathers straight into the MFMA operand layout -- lane (g, c) = (lane >> 4, lane & 15)
+//     loads feature 16 b + c of the eight ratings 8 g .. 8 g + 7 of a 32-rating stage, one
+//     4-byte load per (feature block b, rating): a wave instruction touches four 64-byte
+//     segments of four gathered factor rows.  64-bit lane addresses: no 4 GiB table limit.
+//   * fp32 on the bf16 matrix pipe.  The fp32 MFMA runs at 1/16 of the bf16 rate, and a
+//     16-wide tiling of a 101-column system computes 1.42x the useful flops: at 157 TF that is
+//     9.1 ms per Netflix half-iteration against 5.05 ms of HBM time.  Here every
+//     gathered fp32 value x is split exactly into three bf16 terms x = h + m + l
+//     (round-to-nearest; 8 + 8 + 8 significand bits) and the product of two values is
+//     evaluated as hh + hm + mh + mm + hl + lh on v_mfma_f32_16x16x32_bf16 with fp32
+//     accumulation: the dropped terms (ml, lm, ll) are below 2^-23 of the product, i.e.
+//     below the rounding error of one fp32 fmaf on a sum of two such products.  Every bf16
+//     product is exact in fp32.  Error against an fp64 Gram is the same class as the fmaf
+//     chain's (tests/test_gpu_parity.py::test_split_gram_error_class); the bit-exact fp32
+//     MFMA path stays available (cumf_set_gram_mode / CUMF_ALS_GRAM=exact).
+//   * LU on the accumulators of the one wave: four pivots per step as one rank-4
+//     v_mfma_f32_16x16x4_f32 per live tile (the elimination of lu_solve_mfma, als_kernels.hip),
+//     but the 4 x 4 pivot block comes from v_readlane, the panel rows reach the other lane
+//     groups through ds_bpermute_b32, and nothing waits on another wave.  Back substitution
+//     on the packed row store (back_substitute_zeroed, als_device.h).
+//
+// The accumulator layout (C/D of every 16 x 16 MFMA: lane (g, c), register r = element
+// (4 g + r, c)) and the partial-tile scratch layout are those of als_kernels.hip, so chunked
+// rows go through the same als_reduce_kernel.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+#include "als_device.h"
+#include "als_internal.h"
+
+namespace cumf {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+constexpr int kWaveStage = 32;   // ratings per stage = K of v_mfma_f32_16x16x32_bf16
+constexpr int kZeroFloats = 256; // >= 16 * kMaxWaveNB + 16
+constexpr int kWaveLuDummy = 16 * kMaxWaveNB + 16;  // landing line of the masked-off row-store writes
+
+// Zeros that stand in for "no rating here": ratings past the end of an item gather from
+// this row, the pad lanes of the last feature block read it too.
+static __device__ float g_wave_zeros[kZeroFloats];
+
+// two fp32 -> packed bf16x2 (a in the low half), round to nearest even: v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float bf16_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
+                                                 0);
+}
+
+// ----------------------------------------------------------------------------------
+// One 32-rating stage in flight: the raw gathered values in the operand layout and its
+// column indices.  Planes: the three bf16 terms of a converted stage.
+// ----------------------------------------------------------------------------------
+template <int NB>
+struct WaveStage {
+  float raw[NB][8];  // raw[b][e]: feature 16 b + c of rating 8 g + e
+  float rv[8];       // rating values (lanes of slot f; zeros elsewhere)
+  int idx[8];        // column indices of a stage whose gathers are still to be issued
+};
+template <int NB>
+struct Planes {
+  u32x4 h[NB], m[NB], l[NB];
+};
+
+// Loop-invariant per-lane state of the gather.  FULL forms assume every rating of the stage
+// exists (16-byte index / rating loads, no selects); the generic forms clamp the index loads to
+// the item and point the ratings past its end at the zero row (their rating value may then be
+// anything finite: it only ever meets zeros).
+template <int NB>
+struct WaveGather {
+  const char* lane_base;   // gather table + 4 c
+  const char* zero_base;   // zero row + 4 c
+  const float* val_base;   // val + begin + 8 g in the lanes of slot f, the zero row elsewhere
+  const int* idx_base;     // colidx + begin + 8 g
+  long long last_off;      // last feature block: byte offset of this lane's load from the row pointer
+  unsigned row_bytes;
+  int g, len;
+  bool is_feat, is_val;    // last feature block: this lane holds a feature / the rating slot
+
+  __device__ __forceinline__ void init(const KernelArgs& a, int f, long long begin, int len_, int lane) {
+    const int c = lane & 15;
+    g = lane >> 4;
+    len = len_;
+    row_bytes = (unsigned)f * 4u;
+    lane_base = reinterpret_cast<const char*>(a.gather) + 4 * c;
+    zero_base = reinterpret_cast<const char*>(g_wave_zeros) + 4 * c;
+    const int fi = 16 * (NB - 1) + c;
+    is_feat = fi < f;
+    is_val = fi == f;
+    // lanes behind the features re-read the start of the row (in bounds) and drop the value
+    last_off = is_feat ? 64 * (NB - 1) : -4 * c;
+    val_base = is_val ? a.val + begin + 8 * g : g_wave_zeros;
+    idx_base = a.colidx + begin + 8 * g;
+  }
+
+  template <bool FULL>
+  __device__ __forceinline__ void load_idx(WaveStage<NB>& st, int s) const {
+    const int* p = idx_base + kWaveStage * s;
+    if constexpr (FULL) {
+      const i32x4u lo = *reinterpret_cast<const i32x4u*>(p);
+      const i32x4u hi = *reinterpret_cast<const i32x4u*>(p + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        st.idx[e] = lo[e];
+        st.idx[4 + e] = hi[e];
+      }
+    } else {
+      const int last = len - 1 - (kWaveStage * s + 8 * g);  // offset of the item's last rating from p
+#pragma unroll
+      for (int e = 0; e < 8; ++e) st.idx[e] = p[e < last ? e : last];
+    }
+  }
+
+  // the rating rides in slot f of the last block (als.cu:750-757 fused into the Gram: column f of
+  // the last tile column is sum r * theta = the right-hand side)
+  template <bool FULL>
+  __device__ __forceinline__ void load_val(WaveStage<NB>& st, int s) const {
+    const float* vp = val_base + (is_val ? kWaveStage * s : 0);
+    if constexpr (FULL) {
+      const f32x4u lo = *reinterpret_cast<const f32x4u*>(vp);
+      const f32x4u hi = *reinterpret_cast<const f32x4u*>(vp + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        st.rv[e] = lo[e];
+        st.rv[4 + e] = hi[e];
+      }
+    } else {
+      const int last = is_val ? len - 1 - (kWaveStage * s + 8 * g) : 7;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) st.rv[e] = vp[e < last ? e : last];
+    }
+  }
+
+  // row pointer (+ 4 c) of rating e of stage s, from st.idx
+  template <bool FULL, int E>
+  __device__ __forceinline__ const char* row_ptr(const WaveStage<NB>& st, int s) const {
+    const char* row = lane_base + (unsigned long long)(unsigned)st.idx[E] * row_bytes;  // v_mad_u64_u32
+    if constexpr (!FULL) {
+      const int left = len - (kWaveStage * s + 8 * g);  // ratings of the item from this lane group's first on
+      const char* z = zero_base;
+      row = (E < left) ? row : z;
+    }
+    return row;
+  }
+  template <int B, int E>
+  __device__ __forceinline__ void load_one(WaveStage<NB>& st, const char* row) const {
+    if constexpr (B + 1 < NB)
+      st.raw[B][E] = *reinterpret_cast<const float*>(row + 64 * B);
+    else
+      st.raw[B][E] = *reinterpret_cast<const float*>(row + last_off);
+  }
+  template <bool FULL>
+  __device__ __forceinline__ void issue_all(WaveStage<NB>& st, int s) const {
+    static_for<8>([&](auto ec) {
+      constexpr int E = decltype(ec)::value;
+      const char* row = row_ptr<FULL, E>(st, s);
+      static_for<NB>([&](auto bc) { load_one<decltype(bc)::value, E>(st, row); });
+    });
+    load_val<FULL>(st, s);
+  }
+  // after the loads have landed: the rating / the zero padding into rating E of the last block
+  template <int E>
+  __device__ __forceinline__ void finish_one(WaveStage<NB>& st) const {
+    st.raw[NB - 1][E] = is_feat ? st.raw[NB - 1][E] : st.rv[E];
+  }
+};
+
+// Exact three-way split x = h + m + l of ratings 2 V, 2 V + 1 of feature block B.  x - h and
+// (x - h) - m are exact in fp32 (h carries the leading 8 significand bits of x, m the next 8), and the
+// last residual has at most 8 significant bits, so its conversion is exact too.
+template <int NB, int B, int V>
+__device__ __forceinline__ void split_pair(const WaveStage<NB>& st, Planes<NB>& P) {
+  const float a = st.raw[B][2 * V], b = st.raw[B][2 * V + 1];
+  const unsigned H = pack_bf16(a, b);
+  const float ra = a - bf16_lo(H), rb = b - bf16_hi(H);
+  const unsigned M = pack_bf16(ra, rb);
+  const float la = ra - bf16_lo(M), lb = rb - bf16_hi(M);
+  P.h[B][V] = H;
+  P.m[B][V] = M;
+  P.l[B][V] = pack_bf16(la, lb);
+}
+
+// n-th MFMA of a stage, n in [0, 6 NT): product n / NT of tile n % NT -- consecutive MFMAs hit
+// different accumulators.  tile(I, J) += sum over the 32 ratings of theta[16 I + i] theta[16 J + j]
+// as lh + hl + mm + mh + hm + hh (small terms first).
+template <int NB, int N>
+__device__ __forceinline__ void gram_mfma(const Planes<NB>& P, f32x4 (&acc)[NB * (NB + 1) / 2]) {
+  constexpr int NT = NB * (NB + 1) / 2;
+  constexpr int prod = N / NT, t = N % NT;
+  constexpr int I = tile_I<NB>(t), J = tile_J<NB>(t);
+  if constexpr (prod == 0) acc[t] = mfma_bf16(P.l[I], P.h[J], acc[t]);
+  if constexpr (prod == 1) acc[t] = mfma_bf16(P.h[I], P.l[J], acc[t]);
+  if constexpr (prod == 2) acc[t] = mfma_bf16(P.m[I], P.m[J], acc[t]);
+  if constexpr (prod == 3) acc[t] = mfma_bf16(P.m[I], P.h[J], acc[t]);
+  if constexpr (prod == 4) acc[t] = mfma_bf16(P.h[I], P.m[J], acc[t]);
+  if constexpr (prod == 5) acc[t] = mfma_bf16(P.h[I], P.h[J], acc[t]);
+}
+
+// ----------------------------------------------------------------------------------
+// One step of the software pipeline, pinned slot by slot (sched_barrier): while the 6 NT MFMAs
+// of stage s run on the planes `cur`, the wave
+//   * splits stage s + 1 (gathered during step s - 1, raw in `nxt`) into the planes `pn`,
+//   * issues the gathers of stage s + 2 into the raw buffer of stage s (its values were split
+//     during step s - 1), two 4-byte loads per slot,
+//   * loads the column indices of stage s + 3.
+// 4 NB slots: one pair split (11 VALU) + 2 loads + ~6 MFMAs each -- one wave per SIMD has nobody
+// else to fill the matrix pipe's shadow, so the filler is spread evenly by hand.
+// ----------------------------------------------------------------------------------
+template <int NB, bool FULL>
+__device__ __forceinline__ void pipe_step(const WaveGather<NB>& wg, const Planes<NB>& pc, Planes<NB>& pn,
+                                          WaveStage<NB>& rc, WaveStage<NB>& rn, f32x4 (&acc)[NB * (NB + 1) / 2],
+                                          int s, int nst) {
+  constexpr int NT = NB * (NB + 1) / 2;
+  constexpr int S = 4 * NB;   // slots
+  constexpr int M = 6 * NT;   // MFMAs
+  // stages past the end are clamped to the last one: their loads stay in bounds and nobody uses them
+  const int s2 = FULL ? s + 2 : (s + 2 < nst ? s + 2 : nst - 1);
+  const int s3 = FULL ? s + 3 : (s + 3 < nst ? s + 3 : nst - 1);
+  const char* row = nullptr;
+  static_for<S>([&](auto uc) {
+    constexpr int u = decltype(uc)::value;
+    if constexpr (u == 0) {
+      wg.template load_idx<FULL>(rn, s3);  // rn.idx (stage s + 1) was consumed during step s - 1
+      wg.template load_val<FULL>(rc, s2);  // rc.rv (stage s) likewise
+    }
+    // gathers of stage s + 2: loads 2 u, 2 u + 1 (rating-major)
+    static_for<2>([&](auto kc) {
+      constexpr int k = 2 * u + decltype(kc)::value;
+      constexpr int E = k / NB, B = k % NB;
+      if constexpr (B == 0) row = wg.template row_ptr<FULL, E>(rc, s2);
+      wg.template load_one<B, E>(rc, row);
+    });
+    // split of stage s + 1: pair u % 4 of block u / 4 (the last block first takes its rating / zeros)
+    if constexpr (u / 4 == NB - 1) {
+      wg.template finish_one<2 * (u % 4)>(rn);
+      wg.template finish_one<2 * (u % 4) + 1>(rn);
+    }
+    split_pair<NB, u / 4, u % 4>(rn, pn);
+    // MFMAs of stage s
+    static_for<(u + 1) * M / S - u * M / S>([&](auto nc) { gram_mfma<NB, u * M / S + decltype(nc)::value>(pc, acc); });
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
+// ----------------------------------------------------------------------------------
+// Epilogues on the full tile set of one wave (same element layout as als_kernels.hip).
+// ----------------------------------------------------------------------------------
+template <int NB>
+__device__ __forceinline__ void wave_tiles_to_partial(const f32x4 (&acc)[NB * (NB + 1) / 2], float* __restrict__ part,
+                                                      int lane) {
+  static_for<NB*(NB + 1) / 2>([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[((size_t)t * 4 + r) * 64 + lane] = acc[t][r];
+  });
+}
+
+// row-major f x f Gram, both triangles, lambda * n on the diagonal (als.cu:545-566) + RHS
+template <int NB>
+__device__ __forceinline__ void wave_tiles_to_global(const f32x4 (&acc)[NB * (NB + 1) / 2], float* __restrict__ tt,
+                                                     float* __restrict__ rhs, int f, float reg, int lane) {
+  const int c = lane & 15, kk = lane >> 4;
+  static_for<NB*(NB + 1) / 2>([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    constexpr int I = tile_I<NB>(t), J = tile_J<NB>(t);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * I + 4 * kk + r, j = 16 * J + c;
+      float v = acc[t][r];
+      if (i < f && j < f) {
+        if (i == j) v += reg;
+        tt[(size_t)i * f + j] = v;
+        if (I != J) tt[(size_t)j * f + i] = v;
+      } else if (i < f && j == f && rhs != nullptr) {
+        rhs[i] = v;
+      }
+    }
+  });
+}
+
+// ----------------------------------------------------------------------------------
+// Unpivoted Gaussian elimination of [A | b] on the accumulators of ONE wave + back
+// substitution: the content of cublasSgetrfBatched(PivotArray = NULL) + cublasSgetrsBatched
+// (als.cu:77,98 / 146,166).  Panel of four pivots p0 .. p0 + 3 (block row Ip, lane group q):
+//   1. the 4 x 4 pivot block is read out of the diagonal tile with v_readlane and eliminated on
+//      wave-uniform values (four dependent v_rcp_f32): multipliers, composite multipliers
+//      (rows of the inverse of the panel's unit lower triangle) and -1 / u_kk;
+//   2. per live feature block b the four raw panel rows (registers 0..3 of lane group q of tile
+//      (Ip, b)) are broadcast to all lane groups with ds_bpermute_b32; lane group kk forms the
+//      eliminated row p0 + kk at its columns, ub[b], with three FMAs;
+//   3. rank-4 update of every live tile (I, J), I >= Ip: A operand = -ub[I] / u_kk masked to the
+//      rows below the pivot (symmetry: a_i,pk = u'_k,i), B operand = ub[J];
+//   4. the eliminated rows go to the packed row store (zeros at and left of the diagonal inside
+//      the diagonal block, as back_substitute_zeroed expects), the reciprocals to rdiag.
+// Operation order differs from the oracle's right-looking loop; parity is by tolerance.
+// ----------------------------------------------------------------------------------
+template <int NB, int FC>
+__device__ __forceinline__ void lu_wave(f32x4 (&acc)[NB * (NB + 1) / 2], float* U, float* rdiag, int f_rt, float reg,
+                                        float* __restrict__ x_global, int lane) {
+  const int f = FC ? FC : f_rt;  // FC != 0: compile-time f, the whole elimination is one basic block
+  const int c = lane & 15, kk = (lane >> 4) & 3;
+  const bool k1 = kk == 1, k2 = kk == 2, k3 = kk == 3;
+  auto sel = [](bool p, float a, float b) { return p ? a : b; };  // flat selects: v_cndmask, no branches
+  static_for<NB>([&](auto ic) {
+    constexpr int t = tile_of<NB>(decltype(ic)::value, decltype(ic)::value);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float d = acc[t][r] + reg;  // lambda * n_u on the diagonal (als.cu:545-557)
+      acc[t][r] = sel(4 * kk + r == c, d, acc[t][r]);
+    }
+  });
+  float* zpad = rdiag + ((f + 3) & ~3) + 32;  // 16 zeros for the back substitution (same place as lu_solve_mfma)
+  if (lane < 16) zpad[lane] = 0.f;
+  float* dummy = zpad + 16;  // kWaveLuDummy floats behind the zeros
+
+  auto rl = [](float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+  };
+  auto bperm = [](int addr, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
+  };
+
+  static_for<NB>([&](auto ipc) {
+    constexpr int Ip = decltype(ipc)::value;
+    constexpr int SD = tile_of<NB>(Ip, Ip);
+    static_for<4>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      constexpr int p0 = 16 * Ip + 4 * q;
+      if (p0 < f) {  // wave-uniform (compile-time when FC != 0)
+        // 1. pivot block: rows = registers 0..3 of lane group q, columns = lanes 4 q .. 4 q + 3 of it
+        constexpr int l0 = 20 * q;
+        const bool v1 = p0 + 1 < f, v2 = p0 + 2 < f, v3 = p0 + 3 < f;
+        const bool vk = p0 + kk < f;  // this lane group's pivot exists (short last panel otherwise)
+        float P00 = rl(acc[SD][0], l0), P01 = rl(acc[SD][0], l0 + 1), P02 = rl(acc[SD][0], l0 + 2),
+              P03 = rl(acc[SD][0], l0 + 3);
+        float P11 = rl(acc[SD][1], l0 + 1), P12 = rl(acc[SD][1], l0 + 2), P13 = rl(acc[SD][1], l0 + 3);
+        float P22 = rl(acc[SD][2], l0 + 2), P23 = rl(acc[SD][2], l0 + 3);
+        float P33 = rl(acc[SD][3], l0 + 3);
+        auto recip = [](float d) { return __builtin_amdgcn_rcpf(d); };
+        const float rp0 = recip(P00);
+        const float m10 = -P01 * rp0, m20 = -P02 * rp0, m30 = -P03 * rp0;
+        P11 = fmaf(m10, P01, P11);
+        P12 = fmaf(m10, P02, P12);
+        P13 = fmaf(m10, P03, P13);
+        P22 = fmaf(m20, P02, P22);
+        P23 = fmaf(m20, P03, P23);
+        P33 = fmaf(m30, P03, P33);
+        const float rp1 = recip(sel(v1, P11, 1.0f));
+        const float m21 = -P12 * rp1, m31 = -P13 * rp1;
+        P22 = fmaf(m21, P12, P22);
+        P23 = fmaf(m21, P13, P23);
+        P33 = fmaf(m31, P13, P33);
+        const float rp2 = recip(sel(v2, P22, 1.0f));
+        const float m32 = -P23 * rp2;
+        P33 = fmaf(m32, P23, P33);
+        const float rp3 = recip(sel(v3, P33, 1.0f));
+        const float e20 = fmaf(m21, m10, m20);
+        const float e31 = fmaf(m32, m21, m31);
+        const float e30 = fmaf(m32, e20, fmaf(m31, m10, m30));
+        const float rpk = sel(k3, rp3, sel(k2, rp2, sel(k1, rp1, rp0)));
+        const float c0 = sel(k3, e30, sel(k2, e20, sel(k1, m10, 0.f)));
+        const float c1 = sel(k3, e31, sel(k2, m21, 0.f));
+        const float c2 = sel(k3, m32, 0.f);
+        const float nrp = sel(vk, -rpk, 0.f);
+        // 2. eliminated panel row of this lane group at every live block
+        const int src = 4 * (16 * q + c);  // byte address of lane (q, c) for ds_bpermute
+        float ub[NB];
+        static_for<NB>([&](auto bc) {
+          constexpr int b = decltype(bc)::value;
+          if constexpr (b >= Ip) {
+            constexpr int t = tile_of<NB>(Ip, b);
+            const float R0 = bperm(src, acc[t][0]), R1 = bperm(src, acc[t][1]), R2 = bperm(src, acc[t][2]),
+                        R3 = bperm(src, acc[t][3]);
+            const float own = sel(k3, R3, sel(k2, R2, sel(k1, R1, R0)));
+            ub[b] = fmaf(c2, R2, fmaf(c1, R1, fmaf(c0, R0, own)));
+          }
+        });
+        // 4. final rows into the row store (lanes without a row / column store to a dummy line: no
+        // branch, the elimination stays one basic block)
+        {
+          float* w = vk ? U + lu_row_off<NB>(p0 + kk) + c : dummy + c;
+          static_for<NB>([&](auto bc) {
+            constexpr int b = decltype(bc)::value;
+            if constexpr (b >= Ip) {
+              const float v = sel(b > Ip || c > 4 * q + kk, ub[b], 0.f);
+              if constexpr (b < NB - 1) {
+                w[16 * b] = v;
+              } else {
+                float* wl = (16 * b + c <= f) ? w + 16 * b : dummy + lane;
+                *wl = v;
+              }
+            }
+          });
+          float* rd = (c == 4 && vk) ? rdiag + p0 + kk : dummy + lane;
+          *rd = rpk;
+        }
+        // 3. rank-4 update of the live tiles; block row Ip (which holds the next panel) first so
+        // that the next pivot chain can start while the rest of the update drains
+        static_for<NB>([&](auto i2) {
+          constexpr int I = decltype(i2)::value;
+          if constexpr (I >= Ip) {
+            float la = ub[I] * nrp;
+            if constexpr (I == Ip) la = sel(c > 4 * q + kk, la, 0.f);  // rows at or above the pivot stay
+            static_for<NB>([&](auto j2) {
+              constexpr int J = decltype(j2)::value;
+              if constexpr (J >= I) {
+                constexpr int t = tile_of<NB>(I, J);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(la, ub[J], acc[t], 0, 0, 0);
+              }
+            });
+          }
+        });
+      }
+    });
+  });
+  __syncthreads();  // one wave: orders the row-store writes before the reads below
+  back_substitute_zeroed<NB, (16 * NB + 63) / 64>(U, f, rdiag, zpad, x_global, lane);
+}
+
+// ----------------------------------------------------------------------------------
+// Kernel: one 64-thread workgroup (= one wave) per plan item.  FC != 0: f known at compile time.
+// ----------------------------------------------------------------------------------
+template <int NB, int MODE, int FC>
+__global__ __launch_bounds__(64) void als_wave_kernel(const KernelArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NT = NB * (NB + 1) / 2;
+  const int lane = threadIdx.x;
+  const int item = blockIdx.x;
+  const int row = a.item_row[item];
+  const long long begin = a.item_begin[item];
+  const int len = a.item_len[item];
+  const int slot = a.item_slot[item];
+  const int rowlen = a.item_rowlen[item];
+  const int f = FC ? FC : a.f;
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nst = (len + kWaveStage - 1) / kWaveStage;
+  const int nfull = len / kWaveStage;
+  if (nst > 0) {
+    WaveGather<NB> wg;
+    wg.init(a, f, begin, len, lane);
+    WaveStage<NB> r0, r1;  // raw stages of even / odd index
+    Planes<NB> p0, p1;     // their split forms
+    auto clamp = [&](int s) { return s < nst ? s : nst - 1; };
+    // prologue: gathers of stages 0 and 1 in flight, indices of stage 2, stage 0 split
+    wg.template load_idx<false>(r0, 0);
+    wg.template load_idx<false>(r1, clamp(1));
+    wg.template issue_all<false>(r0, 0);
+    wg.template issue_all<false>(r1, clamp(1));
+    static_for<8>([&](auto ec) { wg.template finish_one<decltype(ec)::value>(r0); });
+    static_for<4 * NB>([&](auto uc) { split_pair<NB, decltype(uc)::value / 4, decltype(uc)::value % 4>(r0, p0); });
+    wg.template load_idx<false>(r0, clamp(2));
+    int s = 0;
+    // stages s + 2 .. s + 4 full: two select-free steps (even + odd) on the ping-pong buffers
+    for (; s + 4 < nfull; s += 2) {
+      pipe_step<NB, true>(wg, p0, p1, r0, r1, acc, s, nst);
+      pipe_step<NB, true>(wg, p1, p0, r1, r0, acc, s + 1, nst);
+    }
+    while (true) {
+      if (s >= nst) break;
+      pipe_step<NB, false>(wg, p0, p1, r0, r1, acc, s, nst);
+      if (++s >= nst) break;
+      pipe_step<NB, false>(wg, p1, p0, r1, r0, acc, s, nst);
+      ++s;
+    }
+  }
+
+  if (slot >= 0) {
+    wave_tiles_to_partial<NB>(acc, a.part + (size_t)slot * NT * 256, lane);
+    return;
+  }
+  const float reg = (float)rowlen * a.lambda;  // als.cu:547: (end - start) * lambda
+  if constexpr (MODE == kModeMaterialize) {
+    float* tt = a.tt + (size_t)(row - a.row_begin) * f * f;
+    float* rhs = a.rhs ? a.rhs + (size_t)(row - a.row_begin) * f : nullptr;
+    wave_tiles_to_global<NB>(acc, tt, rhs, f, reg, lane);
+  } else {
+    lu_wave<NB, FC>(acc, smem, smem + lu_packed_floats(NB), f, reg, a.update + (size_t)row * f, lane);
+  }
+}
+
+// ----------------------------------------------------------------------------------
+// Launcher (called by launch_half_iteration, als_kernels.hip)
+// ----------------------------------------------------------------------------------
+template <int NB, int FC>
+static hipError_t launch_wave_fc(const KernelArgs& a, int mode, long n_items, hipStream_t stream) {
+  if (mode == kModeMaterialize) {
+    hipLaunchKernelGGL((als_wave_kernel<NB, kModeMaterialize, FC>), dim3((unsigned)n_items), dim3(64), 0, stream, a);
+  } else {
+    const size_t lds = (lu_lds_floats(NB, a.f) + kWaveLuDummy) * sizeof(float);
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(als_wave_kernel<NB, kModeLU, FC>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((als_wave_kernel<NB, kModeLU, FC>), dim3((unsigned)n_items), dim3(64), lds, stream, a);
+  }
+  return hipGetLastError();
+}
+
+#ifndef CUMF_WAVE_NB
+#error "compile with -DCUMF_WAVE_NB=<feature blocks>"
+#endif
+
+template <int NB>
+hipError_t wave_item_launch(const KernelArgs& a, int mode, long n_items, hipStream_t stream);
+template <>
+hipError_t wave_item_launch<CUMF_WAVE_NB>(const KernelArgs& a, int mode, long n_items, hipStream_t stream) {
+  if (n_items <= 0) return hipSuccess;
+  if (mode != kModeMaterialize && mode != kModeLU) return hipErrorInvalidValue;
+#if CUMF_WAVE_NB == 7
+  // the reference's own specialisation: get_hermitian100 for f == 100 (als.cu:788-817)
+  if (a.f == 100) return launch_wave_fc<7, 100>(a, mode, n_items, stream);
+#endif
+  return launch_wave_fc<CUMF_WAVE_NB, 0>(a, mode, n_items, stream);
+}
+
+}  // namespace cumf
