@@ -151,6 +151,7 @@ def update_fused(plan: Plan, colidx, val, gather, update, lambda_: float, solver
     import torch
 
     lib = _libmod.load()
+    _libmod.check(lib.cumf_check_gather_table(gather.shape[0], plan.f, _solver_id(solver), 0), "cumf_check_gather_table")
     _libmod.check(lib.cumf_als_update_fused(plan._h, _dp(colidx, torch.int32), _dp(val, torch.float32),
                                             _dp(gather, torch.float32), _dp(update, torch.float32), plan.f,
                                             float(lambda_), _solver_id(solver), int(cg_iters), _stream()),
@@ -164,6 +165,7 @@ def get_hermitian(plan: Plan, colidx, val, gather, lambda_: float, tt=None, rhs=
 
     lib = _libmod.load()
     f, rows = plan.f, plan.batch_rows
+    _libmod.check(lib.cumf_check_gather_table(gather.shape[0], f, SOLVER_LU, 1), "cumf_check_gather_table")
     if tt is None:
         tt = torch.empty((rows, f, f), dtype=torch.float32, device=gather.device)
     if rhs is None and want_rhs:

@@ -100,10 +100,24 @@ SLAB_FILES = {
 }
 
 
+def widen_indptr(indptr32: np.ndarray, nnz: int) -> np.ndarray:
+    """4-byte on-disk row pointers -> int64.  With nnz >= 2^31 the file holds the values modulo 2^32
+    (hugewiki.cu:1973,1984 reads them as unsigned; nnz = 3.1 G wraps once): reinterpret as uint32 and
+    add 2^32 at every wrap (row pointers are non-decreasing).  Raises if the result does not end at nnz."""
+    u = np.ascontiguousarray(indptr32).view(np.uint32).astype(np.int64)
+    if nnz >= 2 ** 31:
+        wraps = np.concatenate([[0], np.cumsum(np.diff(u) < 0)])
+        u = u + (wraps.astype(np.int64) << 32)
+    if u[0] != 0 or u[-1] != nnz or (np.diff(u) < 0).any():
+        raise ValueError(f"row pointers do not describe {nnz} ratings (first {u[0]}, last {u[-1]}): "
+                         "4-byte indptr overflow or wrong nnz")
+    return u
+
+
 def split_dataset(data_dir: str, out_dir: str, gpus: int, m: int, n: int, nnz: int, nnz_test: int):
     """Write per-GPU slab files `<name><g>` (g = 0..gpus-1) and `slabs.txt`; returns the bounds."""
     d = datagen.read_dataset(data_dir, m, n, nnz, nnz_test)
-    rowptr = d["csr_indptr"].astype(np.int64)
+    rowptr = widen_indptr(d["csr_indptr"], nnz)
     bounds = balanced_slabs(rowptr, gpus)
     os.makedirs(out_dir, exist_ok=True)
     for g in range(gpus):

@@ -90,6 +90,9 @@ extern "C" float cumf_doALS_ex(const int* csrRowIndexHostPtr, const int* csrColI
   if (THETA_BATCH < 1) THETA_BATCH = 1;
   if (!cumf::fused_supported(f, solver == CUMF_SOLVER_LU ? cumf::kModeLU : cumf::kModeCG)) fused = 0;  // CG: f <= 128
 
+  // both factor tables are gathered from (Theta by the X update, X by the Theta update)
+  DRV_CHECK(cumf_check_gather_table(n, f, solver, !fused));
+  DRV_CHECK(cumf_check_gather_table(m, f, solver, !fused));
   if (!quiet) printf("*******start allocating memory on GPU...\n");
   int* csrColIndex = to_device(csrColIndexHostPtr, (size_t)nnz);
   float* csrVal = to_device(csrValHostPtr, (size_t)nnz);

@@ -39,7 +39,9 @@ __host__ __device__ constexpr size_t solve_lds_floats(int f, int mode) {
 
 // Which (f, solver) pairs the fused Gram+solve kernel covers.
 __host__ __device__ constexpr bool fused_supported(int f, int mode) {
-  return mode == kModeLU ? nb_for_f(f) <= nb_for_f(kMaxF) : nb_for_f(f) <= kMaxFusedNB;
+  // CG keeps x, r, p, Ap as two registers per lane (elements lane and lane + 64): f <= 128 exactly, not
+  // "NB <= 9" (f = 130..143 has NB = 9 too; found by tests/test_gpu_parity.py::test_doals_large_f)
+  return mode == kModeLU ? nb_for_f(f) <= nb_for_f(kMaxF) : (f <= kVecLd && nb_for_f(f) <= kMaxFusedNB);
 }
 
 struct KernelArgs {

@@ -1361,7 +1361,7 @@ static hipError_t launch_mode(const KernelArgs& a, int mode, long n_items, long 
     return v4 ? launch_nb<NB, f32x4, kModeMaterialize>(a, n_items, n_mrows, stream)
               : launch_nb<NB, f32x2, kModeMaterialize>(a, n_items, n_mrows, stream);
   if constexpr (NB <= kMaxFusedNB) {
-    if (mode == kModeCG)
+    if (mode == kModeCG && a.f <= kVecLd)  // cg_solve_lds holds two vector elements per lane: f <= 128
       return v4 ? launch_nb<NB, f32x4, kModeCG>(a, n_items, n_mrows, stream)
                 : launch_nb<NB, f32x2, kModeCG>(a, n_items, n_mrows, stream);
   }

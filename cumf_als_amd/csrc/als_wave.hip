@@ -47,10 +47,14 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef __attribute__((address_space(3))) float* lds_float_ptr;  // LDS pointer kept in its own address space (M0 operand)
+
+#ifndef CUMF_WAVE_VARIANT
+#define CUMF_WAVE_VARIANT 0  // experiment switches (tools/wave_variants.sh)
+#endif
 
 constexpr int kWaveStage = 32;   // ratings per stage = K of v_mfma_f32_16x16x32_bf16
 constexpr int kZeroFloats = 256; // >= 16 * kMaxWaveNB + 16
-constexpr int kWaveLuDummy = 16 * kMaxWaveNB + 16;  // landing line of the masked-off row-store writes
 
 // Zeros that stand in for "no rating here": ratings past the end of an item gather from
 // this row, the pad lanes of the last feature block read it too.
@@ -96,14 +100,15 @@ struct WaveGather {
   const int* idx_base;     // colidx + begin + 8 g
   long long last_off;      // last feature block: byte offset of this lane's load from the row pointer
   unsigned row_bytes;
-  int g, len;
+  int g, len, dbg;
   bool is_feat, is_val;    // last feature block: this lane holds a feature / the rating slot
 
   __device__ __forceinline__ void init(const KernelArgs& a, int f, long long begin, int len_, int lane) {
     const int c = lane & 15;
     g = lane >> 4;
     len = len_;
-    row_bytes = (unsigned)f * 4u;
+    row_bytes = (a.dbg & 8) ? 0u : (unsigned)f * 4u;  // ablation: every gather hits row 0
+    dbg = a.dbg;
     lane_base = reinterpret_cast<const char*>(a.gather) + 4 * c;
     zero_base = reinterpret_cast<const char*>(g_wave_zeros) + 4 * c;
     const int fi = 16 * (NB - 1) + c;
@@ -180,6 +185,40 @@ struct WaveGather {
     });
     load_val<FULL>(st, s);
   }
+  // ---- prefetch through LDS: global_load_lds_dword writes lane l's dword to (LDS pointer in M0) +
+  // instruction offset + 4 l, so every (rating, feature block) gather of the wave lands as one 256-byte
+  // chunk, in flight without holding registers.  Chunk k = e * NB + b at floats [64 k, 64 k + 64).
+  template <bool FULL>
+  __device__ __forceinline__ void dma_issue(const WaveStage<NB>& st, lds_float_ptr lds, int s) const {
+    using gptr = const __attribute__((address_space(1))) void*;
+    using lptr = __attribute__((address_space(3))) void*;
+    static_for<8>([&](auto ec) {
+      constexpr int E = decltype(ec)::value;
+      const char* row = row_ptr<FULL, E>(st, s);
+      static_for<NB>([&](auto bc) {
+        constexpr int B = decltype(bc)::value;
+        constexpr int k = E * NB + B;
+        if constexpr (B + 1 < NB) {
+          // the instruction offset (64 B: the block's byte offset in the row) moves BOTH addresses:
+          // take it back out of the LDS pointer
+          __builtin_amdgcn_global_load_lds((gptr)row, (lptr)(lds + 64 * k - 16 * B), 4, 64 * B, 0);
+        } else {
+          __builtin_amdgcn_global_load_lds((gptr)(row + last_off), (lptr)(lds + 64 * k), 4, 0, 0);
+        }
+      });
+    });
+  }
+  // chunk -> registers (after s_waitcnt vmcnt(0))
+  __device__ __forceinline__ void dma_read(WaveStage<NB>& st, const float* lds_lane) const {
+    static_for<8>([&](auto ec) {
+      constexpr int E = decltype(ec)::value;
+      static_for<NB>([&](auto bc) {
+        constexpr int B = decltype(bc)::value;
+        st.raw[B][E] = lds_lane[64 * (E * NB + B)];
+      });
+    });
+  }
+
   // after the loads have landed: the rating / the zero padding into rating E of the last block
   template <int E>
   __device__ __forceinline__ void finish_one(WaveStage<NB>& st) const {
@@ -189,17 +228,39 @@ struct WaveGather {
 
 // Exact three-way split x = h + m + l of ratings 2 V, 2 V + 1 of feature block B.  x - h and
 // (x - h) - m are exact in fp32 (h carries the leading 8 significand bits of x, m the next 8), and the
-// last residual has at most 8 significant bits, so its conversion is exact too.
+// last residual has at most 8 significant bits, so its conversion is exact too.  Cut into six
+// micro-steps of 1-3 VALU instructions so that the pipeline can drop one behind every MFMA.
+struct SplitState {
+  float a, b, ra, rb, ta, tb;
+  unsigned H, M;
+};
+template <int NB, int B, int V, int STEP>
+__device__ __forceinline__ void split_micro(const WaveStage<NB>& st, Planes<NB>& P, SplitState& x) {
+  if constexpr (STEP == 0) {
+    x.a = st.raw[B][2 * V];
+    x.b = st.raw[B][2 * V + 1];
+    x.H = pack_bf16(x.a, x.b);
+  } else if constexpr (STEP == 1) {
+    x.ta = bf16_lo(x.H);
+    x.tb = bf16_hi(x.H);
+  } else if constexpr (STEP == 2) {
+    x.ra = x.a - x.ta;
+    x.rb = x.b - x.tb;
+  } else if constexpr (STEP == 3) {
+    x.M = pack_bf16(x.ra, x.rb);
+  } else if constexpr (STEP == 4) {
+    x.ta = bf16_lo(x.M);
+    x.tb = bf16_hi(x.M);
+  } else {
+    P.h[B][V] = x.H;
+    P.m[B][V] = x.M;
+    P.l[B][V] = pack_bf16(x.ra - x.ta, x.rb - x.tb);
+  }
+}
 template <int NB, int B, int V>
 __device__ __forceinline__ void split_pair(const WaveStage<NB>& st, Planes<NB>& P) {
-  const float a = st.raw[B][2 * V], b = st.raw[B][2 * V + 1];
-  const unsigned H = pack_bf16(a, b);
-  const float ra = a - bf16_lo(H), rb = b - bf16_hi(H);
-  const unsigned M = pack_bf16(ra, rb);
-  const float la = ra - bf16_lo(M), lb = rb - bf16_hi(M);
-  P.h[B][V] = H;
-  P.m[B][V] = M;
-  P.l[B][V] = pack_bf16(la, lb);
+  SplitState x;
+  static_for<6>([&](auto sc) { split_micro<NB, B, V, decltype(sc)::value>(st, P, x); });
 }
 
 // n-th MFMA of a stage, n in [0, 6 NT): product n / NT of tile n % NT -- consecutive MFMAs hit
@@ -219,49 +280,35 @@ __device__ __forceinline__ void gram_mfma(const Planes<NB>& P, f32x4 (&acc)[NB *
 }
 
 // ----------------------------------------------------------------------------------
-// One step of the software pipeline, pinned slot by slot (sched_barrier): while the 6 NT MFMAs
-// of stage s run on the planes `cur`, the wave
-//   * splits stage s + 1 (gathered during step s - 1, raw in `nxt`) into the planes `pn`,
-//   * issues the gathers of stage s + 2 into the raw buffer of stage s (its values were split
-//     during step s - 1), two 4-byte loads per slot,
-//   * loads the column indices of stage s + 3.
-// 4 NB slots: one pair split (11 VALU) + 2 loads + ~6 MFMAs each -- one wave per SIMD has nobody
-// else to fill the matrix pipe's shadow, so the filler is spread evenly by hand.
+// One stage, sized for TWO waves per SIMD (<= 256 registers per lane).  A wave cannot hide its own
+// VALU work behind its own 16-cycle MFMAs (measured: stage time = MFMA time + VALU time with one
+// wave per SIMD, whatever the interleave), so the overlap comes from the partner wave: this
+// wave's split burst runs under the partner's MFMA phase and vice versa.  The gather latency
+// (~4 000 cycles under load, measured) is covered by prefetching the NEXT stage through LDS
+// (global_load_lds: no registers in flight) before the split + MFMAs of this one:
+//   wait for the chunks of stage s -> registers -> issue the chunks of stage s + 1 -> split ->
+//   6 NT MFMAs.
 // ----------------------------------------------------------------------------------
-template <int NB, bool FULL>
-__device__ __forceinline__ void pipe_step(const WaveGather<NB>& wg, const Planes<NB>& pc, Planes<NB>& pn,
-                                          WaveStage<NB>& rc, WaveStage<NB>& rn, f32x4 (&acc)[NB * (NB + 1) / 2],
-                                          int s, int nst) {
+template <int NB, int PROD>
+__device__ __forceinline__ void gram_product(const Planes<NB>& P, f32x4 (&acc)[NB * (NB + 1) / 2]) {
   constexpr int NT = NB * (NB + 1) / 2;
-  constexpr int S = 4 * NB;   // slots
-  constexpr int M = 6 * NT;   // MFMAs
-  // stages past the end are clamped to the last one: their loads stay in bounds and nobody uses them
-  const int s2 = FULL ? s + 2 : (s + 2 < nst ? s + 2 : nst - 1);
-  const int s3 = FULL ? s + 3 : (s + 3 < nst ? s + 3 : nst - 1);
-  const char* row = nullptr;
-  static_for<S>([&](auto uc) {
-    constexpr int u = decltype(uc)::value;
-    if constexpr (u == 0) {
-      wg.template load_idx<FULL>(rn, s3);  // rn.idx (stage s + 1) was consumed during step s - 1
-      wg.template load_val<FULL>(rc, s2);  // rc.rv (stage s) likewise
-    }
-    // gathers of stage s + 2: loads 2 u, 2 u + 1 (rating-major)
-    static_for<2>([&](auto kc) {
-      constexpr int k = 2 * u + decltype(kc)::value;
-      constexpr int E = k / NB, B = k % NB;
-      if constexpr (B == 0) row = wg.template row_ptr<FULL, E>(rc, s2);
-      wg.template load_one<B, E>(rc, row);
-    });
-    // split of stage s + 1: pair u % 4 of block u / 4 (the last block first takes its rating / zeros)
-    if constexpr (u / 4 == NB - 1) {
-      wg.template finish_one<2 * (u % 4)>(rn);
-      wg.template finish_one<2 * (u % 4) + 1>(rn);
-    }
-    split_pair<NB, u / 4, u % 4>(rn, pn);
-    // MFMAs of stage s
-    static_for<(u + 1) * M / S - u * M / S>([&](auto nc) { gram_mfma<NB, u * M / S + decltype(nc)::value>(pc, acc); });
-    __builtin_amdgcn_sched_barrier(0);
-  });
+  static_for<NT>([&](auto tc) { gram_mfma<NB, PROD * NT + decltype(tc)::value>(P, acc); });
+}
+
+template <int NB, bool FULL>
+__device__ __forceinline__ void stage_step(const WaveGather<NB>& wg, Planes<NB>& P, WaveStage<NB>& R, lds_float_ptr lds,
+                                           const float* lds_lane, f32x4 (&acc)[NB * (NB + 1) / 2], int s_next,
+                                           int s_idx) {
+  // in flight: chunks + ratings of the stage that is multiplied now, indices of stage s_next
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the LDS-DMA chunks have landed
+  wg.dma_read(R, lds_lane);
+  static_for<8>([&](auto ec) { wg.template finish_one<decltype(ec)::value>(R); });  // consumes R.rv
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the chunks are in registers, the buffer is free
+  if (!(wg.dbg & 16)) wg.template dma_issue<FULL>(R, lds, s_next);                     // consumes R.idx
+  wg.template load_val<FULL>(R, s_next);
+  wg.template load_idx<FULL>(R, s_idx);
+  static_for<4 * NB>([&](auto uc) { split_pair<NB, decltype(uc)::value / 4, decltype(uc)::value % 4>(R, P); });
+  static_for<6>([&](auto pc) { gram_product<NB, decltype(pc)::value>(P, acc); });
 }
 
 // ----------------------------------------------------------------------------------
@@ -301,6 +348,109 @@ __device__ __forceinline__ void wave_tiles_to_global(const f32x4 (&acc)[NB * (NB
 }
 
 // ----------------------------------------------------------------------------------
+// Back substitution U x = y straight from the accumulators of one wave, through a small LDS
+// window (16 NB rows x 17 floats = 7.6 KB at NB = 7 instead of the 29 KB packed row store, so
+// that eight waves fit a CU).  After the elimination tile (I, J), I <= J, holds U (rows above
+// and on the diagonal) in the C/D layout and column f holds y.  Same recurrence as
+// back_substitute_zeroed (als_device.h): lane i owns rows i, i + 64, ...; row i is scaled by
+// 1 / u_ii (z_i = y_i / u_ii, v_ik = u_ik / u_ii), x_k = z_k; per 16-pivot block column kb the
+// tiles (0..kb, kb) are written to the window (entries at and left of the diagonal as zeros) and
+// every lane reads the 16 entries of its rows in that block column, one block ahead of their use
+// (LDS operations of one wave execute in order: the window is rewritten behind the reads).
+// ----------------------------------------------------------------------------------
+constexpr int kBsPitch = 17;
+template <int NB>
+__host__ __device__ constexpr int wave_lu_lds_floats(int f) {
+  return 16 * NB * kBsPitch + ((f + 3) & ~3) + 16;  // window + pivot reciprocals + 16 zeros
+}
+template <int NB>
+__host__ __device__ constexpr int wave_stage_lds_floats() { return 64 * 8 * NB; }  // 8 NB chunks of 64 floats
+
+template <int NB, int NQ>
+__device__ __forceinline__ void back_substitute_tiles(const f32x4 (&acc)[NB * (NB + 1) / 2], float* T,
+                                                      const float* rdiag, const float* zpad, int f,
+                                                      float* __restrict__ x_global, int lane) {
+  const int c = lane & 15, g = lane >> 4;
+  const int top = f - 1;
+  // block column kb -> window
+  auto dump = [&](auto kbc) {
+    constexpr int kb = decltype(kbc)::value;
+    static_for<kb + 1>([&](auto ic) {
+      constexpr int I = decltype(ic)::value;
+      constexpr int t = tile_of<NB>(I, kb);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[t][r];
+        if constexpr (I == kb) v = (c > 4 * g + r) ? v : 0.f;
+        T[(16 * I + 4 * g + r) * kBsPitch + c] = v;
+      }
+    });
+  };
+  float z[NQ], rdl[NQ];
+  const float* rowp[NQ];
+  int ib[NQ];  // block of this lane's row
+  static_for<NQ>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    const int i = lane + 64 * q;
+    const int ic = i < f ? i : f - 1;
+    ib[q] = i < f ? (i >> 4) : 1 << 20;  // rows past f never take part
+    rowp[q] = T + ic * kBsPitch;
+    rdl[q] = i < f ? rdiag[ic] : 0.f;
+  });
+  float col[2][16][NQ];
+  auto issue = [&](auto kbc, auto bufc) {
+    constexpr int kb = decltype(kbc)::value, buf = decltype(bufc)::value, Q = kb >> 2;
+    const float* base[Q + 1];
+    static_for<Q + 1>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      base[q] = (ib[q] > kb) ? zpad : rowp[q];
+    });
+    static_for<16>([&](auto jc) {  // issued in the order they are consumed (LDS returns in order)
+      constexpr int j = 15 - decltype(jc)::value;
+      static_for<Q + 1>([&](auto qc) { col[buf][j][decltype(qc)::value] = base[decltype(qc)::value][j]; });
+    });
+  };
+  // y sits in column f of the last block column
+  dump(std::integral_constant<int, NB - 1>{});
+  static_for<NQ>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    z[q] = rowp[q][f - 16 * (NB - 1)] * rdl[q];
+  });
+  constexpr int NBLK = NB;
+  static_for<NBLK>([&](auto bc) {
+    constexpr int n = decltype(bc)::value;
+    constexpr int kb = NBLK - 1 - n;
+    constexpr int buf = n & 1;
+    constexpr int Q = kb >> 2;  // pivots of this block live in z[Q]
+    if constexpr (Q < NQ) {
+      if constexpr (n == 0) issue(std::integral_constant<int, kb>{}, std::integral_constant<int, buf>{});
+      if constexpr (kb > 0) {
+        dump(std::integral_constant<int, kb - 1>{});
+        issue(std::integral_constant<int, kb - 1>{}, std::integral_constant<int, buf ^ 1>{});
+      }
+      if (16 * kb <= top) {  // uniform: the last block column may hold nothing but y
+        static_for<16>([&](auto jc) {
+          constexpr int j = 15 - decltype(jc)::value;
+          const int k = 16 * kb + j;
+          if (k <= top) {  // uniform; only the last block can be short
+            const float xk = __builtin_bit_cast(
+                float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z[Q]), k & 63));
+            static_for<Q + 1>([&](auto qc) {
+              constexpr int q = decltype(qc)::value;
+              z[q] = fmaf(-(col[buf][j][q] * rdl[q]), xk, z[q]);
+            });
+          }
+        });
+      }
+    }
+  });
+  static_for<NQ>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    if (lane + 64 * q < f) x_global[lane + 64 * q] = z[q];
+  });
+}
+
+// ----------------------------------------------------------------------------------
 // Unpivoted Gaussian elimination of [A | b] on the accumulators of ONE wave + back
 // substitution: the content of cublasSgetrfBatched(PivotArray = NULL) + cublasSgetrsBatched
 // (als.cu:77,98 / 146,166).  Panel of four pivots p0 .. p0 + 3 (block row Ip, lane group q):
@@ -317,12 +467,13 @@ __device__ __forceinline__ void wave_tiles_to_global(const f32x4 (&acc)[NB * (NB
 // Operation order differs from the oracle's right-looking loop; parity is by tolerance.
 // ----------------------------------------------------------------------------------
 template <int NB, int FC>
-__device__ __forceinline__ void lu_wave(f32x4 (&acc)[NB * (NB + 1) / 2], float* U, float* rdiag, int f_rt, float reg,
+__device__ __forceinline__ void lu_wave(f32x4 (&acc)[NB * (NB + 1) / 2], float* T, int f_rt, float reg,
                                         float* __restrict__ x_global, int lane) {
   const int f = FC ? FC : f_rt;  // FC != 0: compile-time f, the whole elimination is one basic block
   const int c = lane & 15, kk = (lane >> 4) & 3;
   const bool k1 = kk == 1, k2 = kk == 2, k3 = kk == 3;
   auto sel = [](bool p, float a, float b) { return p ? a : b; };  // flat selects: v_cndmask, no branches
+  const float e1c = k1 ? 1.0f : 0.f, e2c = k2 ? 1.0f : 0.f, e3c = k3 ? 1.0f : 0.f;  // unit diagonal of E
   static_for<NB>([&](auto ic) {
     constexpr int t = tile_of<NB>(decltype(ic)::value, decltype(ic)::value);
 #pragma unroll
@@ -331,9 +482,9 @@ __device__ __forceinline__ void lu_wave(f32x4 (&acc)[NB * (NB + 1) / 2], float* 
       acc[t][r] = sel(4 * kk + r == c, d, acc[t][r]);
     }
   });
-  float* zpad = rdiag + ((f + 3) & ~3) + 32;  // 16 zeros for the back substitution (same place as lu_solve_mfma)
+  float* rdiag = T + 16 * NB * kBsPitch;  // pivot reciprocals, then 16 zeros (rows outside a pivot block read these)
+  float* zpad = rdiag + ((f + 3) & ~3);
   if (lane < 16) zpad[lane] = 0.f;
-  float* dummy = zpad + 16;  // kWaveLuDummy floats behind the zeros
 
   auto rl = [](float v, int l) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
@@ -349,6 +500,18 @@ __device__ __forceinline__ void lu_wave(f32x4 (&acc)[NB * (NB + 1) / 2], float* 
       constexpr int q = decltype(qc)::value;
       constexpr int p0 = 16 * Ip + 4 * q;
       if (p0 < f) {  // wave-uniform (compile-time when FC != 0)
+        // 2a. raw panel rows of lane group q to every lane group (ds_bpermute: no LDS memory), issued
+        // first: their latency hides behind the pivot chain
+        const int src = 4 * (16 * q + c);  // byte address of lane (q, c)
+        float R[NB][4];
+        static_for<NB>([&](auto bc) {
+          constexpr int b = decltype(bc)::value;
+          if constexpr (b >= Ip) {
+            constexpr int t = tile_of<NB>(Ip, b);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) R[b][r] = bperm(src, acc[t][r]);
+          }
+        });
         // 1. pivot block: rows = registers 0..3 of lane group q, columns = lanes 4 q .. 4 q + 3 of it
         constexpr int l0 = 20 * q;
         const bool v1 = p0 + 1 < f, v2 = p0 + 2 < f, v3 = p0 + 3 < f;
@@ -380,42 +543,21 @@ __device__ __forceinline__ void lu_wave(f32x4 (&acc)[NB * (NB + 1) / 2], float* 
         const float e31 = fmaf(m32, m21, m31);
         const float e30 = fmaf(m32, e20, fmaf(m31, m10, m30));
         const float rpk = sel(k3, rp3, sel(k2, rp2, sel(k1, rp1, rp0)));
-        const float c0 = sel(k3, e30, sel(k2, e20, sel(k1, m10, 0.f)));
-        const float c1 = sel(k3, e31, sel(k2, m21, 0.f));
-        const float c2 = sel(k3, m32, 0.f);
+        // row kk of E = (unit lower triangle of the panel)^-1: eliminated row kk = sum_j E[kk][j] raw_j
+        const float e0 = sel(k3, e30, sel(k2, e20, sel(k1, m10, 1.0f)));
+        const float e1 = sel(k3, e31, sel(k2, m21, e1c));
+        const float e2 = sel(k3, m32, e2c);
         const float nrp = sel(vk, -rpk, 0.f);
-        // 2. eliminated panel row of this lane group at every live block
-        const int src = 4 * (16 * q + c);  // byte address of lane (q, c) for ds_bpermute
+        // 2. eliminated panel row of this lane group at every live block (the broadcasts were issued
+        // ahead of the pivot chain)
         float ub[NB];
         static_for<NB>([&](auto bc) {
           constexpr int b = decltype(bc)::value;
-          if constexpr (b >= Ip) {
-            constexpr int t = tile_of<NB>(Ip, b);
-            const float R0 = bperm(src, acc[t][0]), R1 = bperm(src, acc[t][1]), R2 = bperm(src, acc[t][2]),
-                        R3 = bperm(src, acc[t][3]);
-            const float own = sel(k3, R3, sel(k2, R2, sel(k1, R1, R0)));
-            ub[b] = fmaf(c2, R2, fmaf(c1, R1, fmaf(c0, R0, own)));
-          }
+          if constexpr (b >= Ip) ub[b] = fmaf(e3c, R[b][3], fmaf(e2, R[b][2], fmaf(e1, R[b][1], e0 * R[b][0])));
         });
-        // 4. final rows into the row store (lanes without a row / column store to a dummy line: no
-        // branch, the elimination stays one basic block)
-        {
-          float* w = vk ? U + lu_row_off<NB>(p0 + kk) + c : dummy + c;
-          static_for<NB>([&](auto bc) {
-            constexpr int b = decltype(bc)::value;
-            if constexpr (b >= Ip) {
-              const float v = sel(b > Ip || c > 4 * q + kk, ub[b], 0.f);
-              if constexpr (b < NB - 1) {
-                w[16 * b] = v;
-              } else {
-                float* wl = (16 * b + c <= f) ? w + 16 * b : dummy + lane;
-                *wl = v;
-              }
-            }
-          });
-          float* rd = (c == 4 && vk) ? rdiag + p0 + kk : dummy + lane;
-          *rd = rpk;
-        }
+        // 4. the eliminated rows stay in the accumulators (the update below leaves rows at and above a
+        // pivot alone); only the pivot reciprocals go to LDS, for the back substitution
+        if (c == 4 && vk) rdiag[p0 + kk] = rpk;
         // 3. rank-4 update of the live tiles; block row Ip (which holds the next panel) first so
         // that the next pivot chain can start while the rest of the update drains
         static_for<NB>([&](auto i2) {
@@ -432,18 +574,23 @@ __device__ __forceinline__ void lu_wave(f32x4 (&acc)[NB * (NB + 1) / 2], float* 
             });
           }
         });
+#if !(CUMF_WAVE_VARIANT & 1)
+        // no instruction motion across panels: left free, the scheduler hoists the next panels' broadcasts
+        // until the accumulators spill (measured: Theta side 13.3 -> 12.3 ms with the barrier)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
       }
     });
   });
-  __syncthreads();  // one wave: orders the row-store writes before the reads below
-  back_substitute_zeroed<NB, (16 * NB + 63) / 64>(U, f, rdiag, zpad, x_global, lane);
+  __syncthreads();  // one wave: orders the rdiag writes before the reads below
+  back_substitute_tiles<NB, (16 * NB + 63) / 64>(acc, T, rdiag, zpad, f, x_global, lane);
 }
 
 // ----------------------------------------------------------------------------------
 // Kernel: one 64-thread workgroup (= one wave) per plan item.  FC != 0: f known at compile time.
 // ----------------------------------------------------------------------------------
 template <int NB, int MODE, int FC>
-__global__ __launch_bounds__(64) void als_wave_kernel(const KernelArgs a) {
+__global__ __launch_bounds__(64, 2) void als_wave_kernel(const KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = NB * (NB + 1) / 2;
   const int lane = threadIdx.x;
@@ -454,40 +601,42 @@ __global__ __launch_bounds__(64) void als_wave_kernel(const KernelArgs a) {
   const int slot = a.item_slot[item];
   const int rowlen = a.item_rowlen[item];
   const int f = FC ? FC : a.f;
+  // Two waves share a SIMD.  Left alone they fall into lockstep (both in their MFMA phase, then both
+  // in their split phase: matrix pipe and VALU port each idle half of the time).  A static priority for
+  // the wave in the odd hardware slot breaks the symmetry: it runs at single-wave speed and the
+  // other one fills the matrix pipe whenever the first is splitting (MI355X_MICROARCH.md, "Two waves
+  // per SIMD", item 4).  a.dbg & 4 turns it off (ablation).
+  if (!(a.dbg & 4)) {
+    const unsigned wave_slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);  // HW_REG_HW_ID.WAVE_ID
+    if (wave_slot & 1) __builtin_amdgcn_s_setprio(1);
+  }
 
   f32x4 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nst = (len + kWaveStage - 1) / kWaveStage;
+  // a.dbg: ablation switches for profiling (CUMF_ALS_DBG; results are wrong): 2 = no Gram pass
+  const int nst = (a.dbg & 2) ? 0 : (len + kWaveStage - 1) / kWaveStage;
   const int nfull = len / kWaveStage;
   if (nst > 0) {
     WaveGather<NB> wg;
     wg.init(a, f, begin, len, lane);
-    WaveStage<NB> r0, r1;  // raw stages of even / odd index
-    Planes<NB> p0, p1;     // their split forms
+    WaveStage<NB> R;
+    Planes<NB> P;
+    lds_float_ptr lds = (lds_float_ptr)smem;  // staging chunks of this wave (the LU window aliases them later)
+    const float* lds_lane = smem + lane;
     auto clamp = [&](int s) { return s < nst ? s : nst - 1; };
-    // prologue: gathers of stages 0 and 1 in flight, indices of stage 2, stage 0 split
-    wg.template load_idx<false>(r0, 0);
-    wg.template load_idx<false>(r1, clamp(1));
-    wg.template issue_all<false>(r0, 0);
-    wg.template issue_all<false>(r1, clamp(1));
-    static_for<8>([&](auto ec) { wg.template finish_one<decltype(ec)::value>(r0); });
-    static_for<4 * NB>([&](auto uc) { split_pair<NB, decltype(uc)::value / 4, decltype(uc)::value % 4>(r0, p0); });
-    wg.template load_idx<false>(r0, clamp(2));
+    // prologue: chunks + ratings of stage 0 in flight, indices of stage 1
+    wg.template load_idx<false>(R, 0);
+    wg.template dma_issue<false>(R, lds, 0);
+    wg.template load_val<false>(R, 0);
+    wg.template load_idx<false>(R, clamp(1));
     int s = 0;
-    // stages s + 2 .. s + 4 full: two select-free steps (even + odd) on the ping-pong buffers
-    for (; s + 4 < nfull; s += 2) {
-      pipe_step<NB, true>(wg, p0, p1, r0, r1, acc, s, nst);
-      pipe_step<NB, true>(wg, p1, p0, r1, r0, acc, s + 1, nst);
-    }
-    while (true) {
-      if (s >= nst) break;
-      pipe_step<NB, false>(wg, p0, p1, r0, r1, acc, s, nst);
-      if (++s >= nst) break;
-      pipe_step<NB, false>(wg, p1, p0, r1, r0, acc, s, nst);
-      ++s;
-    }
+    // stages s + 1, s + 2 full: select-free steps.  Past the end the loads are re-issued on the
+    // last stage (in bounds, never used): the step stays branch-free.
+    for (; s + 2 < nfull; ++s) stage_step<NB, true>(wg, P, R, lds, lds_lane, acc, s + 1, s + 2);
+    for (; s < nst; ++s) stage_step<NB, false>(wg, P, R, lds, lds_lane, acc, clamp(s + 1), clamp(s + 2));
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // the last (unused) prefetch must land before the window is reused
   }
 
   if (slot >= 0) {
@@ -495,12 +644,19 @@ __global__ __launch_bounds__(64) void als_wave_kernel(const KernelArgs a) {
     return;
   }
   const float reg = (float)rowlen * a.lambda;  // als.cu:547: (end - start) * lambda
+  if (a.dbg & 1) {  // ablation: no solve (keep the accumulators alive)
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) sum += (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]);
+    if (lane < f) a.update[(size_t)row * f + lane] = sum;
+    return;
+  }
   if constexpr (MODE == kModeMaterialize) {
     float* tt = a.tt + (size_t)(row - a.row_begin) * f * f;
     float* rhs = a.rhs ? a.rhs + (size_t)(row - a.row_begin) * f : nullptr;
     wave_tiles_to_global<NB>(acc, tt, rhs, f, reg, lane);
   } else {
-    lu_wave<NB, FC>(acc, smem, smem + lu_packed_floats(NB), f, reg, a.update + (size_t)row * f, lane);
+    lu_wave<NB, FC>(acc, smem, f, reg, a.update + (size_t)row * f, lane);
   }
 }
 
@@ -509,10 +665,13 @@ __global__ __launch_bounds__(64) void als_wave_kernel(const KernelArgs a) {
 // ----------------------------------------------------------------------------------
 template <int NB, int FC>
 static hipError_t launch_wave_fc(const KernelArgs& a, int mode, long n_items, hipStream_t stream) {
+  const size_t stage_lds = wave_stage_lds_floats<NB>() * sizeof(float);
   if (mode == kModeMaterialize) {
-    hipLaunchKernelGGL((als_wave_kernel<NB, kModeMaterialize, FC>), dim3((unsigned)n_items), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL((als_wave_kernel<NB, kModeMaterialize, FC>), dim3((unsigned)n_items), dim3(64), stage_lds, stream,
+                       a);
   } else {
-    const size_t lds = (lu_lds_floats(NB, a.f) + kWaveLuDummy) * sizeof(float);
+    const size_t lu_lds = wave_lu_lds_floats<NB>(a.f) * sizeof(float);
+    const size_t lds = lu_lds > stage_lds ? lu_lds : stage_lds;
     if (lds > 64 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(als_wave_kernel<NB, kModeLU, FC>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -526,6 +685,9 @@ static hipError_t launch_wave_fc(const KernelArgs& a, int mode, long n_items, hi
 #ifndef CUMF_WAVE_NB
 #error "compile with -DCUMF_WAVE_NB=<feature blocks>"
 #endif
+#ifndef CUMF_WAVE_VARIANT
+#define CUMF_WAVE_VARIANT 0  // experiment switches (tools/wave_variants.sh)
+#endif
 
 template <int NB>
 hipError_t wave_item_launch(const KernelArgs& a, int mode, long n_items, hipStream_t stream);
@@ -533,7 +695,7 @@ template <>
 hipError_t wave_item_launch<CUMF_WAVE_NB>(const KernelArgs& a, int mode, long n_items, hipStream_t stream) {
   if (n_items <= 0) return hipSuccess;
   if (mode != kModeMaterialize && mode != kModeLU) return hipErrorInvalidValue;
-#if CUMF_WAVE_NB == 7
+#if CUMF_WAVE_NB == 7 && !(CUMF_WAVE_VARIANT & 2)
   // the reference's own specialisation: get_hermitian100 for f == 100 (als.cu:788-817)
   if (a.f == 100) return launch_wave_fc<7, 100>(a, mode, n_items, stream);
 #endif

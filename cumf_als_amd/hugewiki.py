@@ -71,7 +71,7 @@ def run(split_dir: str, n: int, f: int, lam: float, iters: int, solver: str = "c
             print("--------- Train RMSE in iter %d: %f" % (it, tr))
             print("--------- Test RMSE in iter %d: %f" % (it, te), flush=True)
     if rank == 0 and not quiet:
-        print("\\ndoALS takes seconds: %.3f for F = %d on %d GPU(s)" % (time.time() - t0, f, world))
+        print("\ndoALS takes seconds: %.3f for F = %d on %d GPU(s)" % (time.time() - t0, f, world))
     return eng, log
 
 

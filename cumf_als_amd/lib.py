@@ -20,7 +20,7 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 C_SYMBOLS = [
     "cumf_doALS", "cumf_doALS_ex", "cumf_plan_create", "cumf_plan_destroy", "cumf_plan_info",
     "cumf_als_update_fused", "cumf_get_hermitian", "cumf_cg_solve_batched", "cumf_lu_solve_batched",
-    "cumf_sse", "cumf_set_gram_mode", "cumf_get_gram_mode", "cumf_set_kernel_timing", "cumf_last_kernel_ms", "cumf_rand_init", "cumf_als_version", "cumf_als_arch",
+    "cumf_sse", "cumf_set_gram_mode", "cumf_get_gram_mode", "cumf_check_gather_table", "cumf_set_kernel_timing", "cumf_last_kernel_ms", "cumf_rand_init", "cumf_als_version", "cumf_als_arch",
 ]
 # C++-linkage drop-in symbols (include/als.h, include/cg.h) under the reference's mangled names
 CXX_SYMBOLS = [
@@ -74,6 +74,8 @@ def load():
     lib.cumf_set_gram_mode.restype = C.c_int
     lib.cumf_set_gram_mode.argtypes = [C.c_int]
     lib.cumf_get_gram_mode.restype = C.c_int
+    lib.cumf_check_gather_table.restype = C.c_int
+    lib.cumf_check_gather_table.argtypes = [C.c_long, C.c_int, C.c_int, C.c_int]
     lib.cumf_set_kernel_timing.restype = C.c_int
     lib.cumf_set_kernel_timing.argtypes = [C.c_int]
     lib.cumf_last_kernel_ms.restype = C.c_int

@@ -129,6 +129,10 @@ int cumf_sse(const float* val, const int* row, const int* col, const float* thet
  * first half-iteration.
  */
 enum { CUMF_GRAM_AUTO = 0, CUMF_GRAM_EXACT = 1 };
+/* 0 when a table of gather_rows x f floats can be gathered by the kernels that (solver, f,
+ * materialize) select; an error (message on stderr) when that path addresses the table with 32-bit
+ * byte offsets and the table is 4 GiB or larger.  doALS and the Python wrappers call it. */
+int cumf_check_gather_table(long gather_rows, int f, int solver, int materialize);
 int cumf_set_gram_mode(int mode);
 int cumf_get_gram_mode(void);
 

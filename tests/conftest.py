@@ -28,3 +28,15 @@ def alslib():
     if not os.path.exists(lib.LIB_PATH):
         lib.build()
     return lib.load()
+
+
+@pytest.fixture
+def gram_mode(request, alslib):
+    """Select the Gram arithmetic for one test ("exact" = fp32 MFMA / fmaf-chain bits, "auto" =
+    bf16x3 split where the wave kernels exist); always restored to the default afterwards."""
+    from cumf_als_amd import als
+
+    mode = getattr(request, "param", "auto")
+    als.set_gram_mode(mode)
+    yield mode
+    als.set_gram_mode("auto")

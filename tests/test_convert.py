@@ -104,3 +104,20 @@ def test_split_slabs_reassemble(tmp_path):
         for c in range(r.n):
             seg = s["csc_indices"][s["csc_indptr"][c]:s["csc_indptr"][c + 1]]
             assert np.all(np.diff(seg) > 0)
+
+
+def test_widen_indptr_above_2_31():
+    """a global row pointer above 2^31 (hugewiki: 3.1 G ratings) is stored modulo 2^32 in
+    the 4-byte file; the splitter must recover it instead of wrapping negative."""
+    from cumf_als_amd import convert
+
+    true = np.array([0, 2 ** 31 - 5, 2 ** 31 + 7, 3_101_144_313, 2 ** 32 - 1, 2 ** 32 + 10, 5_000_000_000],
+                    dtype=np.int64)
+    on_disk = (true % 2 ** 32).astype(np.uint32).view(np.int32)
+    assert (on_disk < 0).any()
+    got = convert.widen_indptr(on_disk, int(true[-1]))
+    np.testing.assert_array_equal(got, true)
+    with pytest.raises(ValueError):
+        convert.widen_indptr(on_disk, int(true[-1]) + 1)
+    small = np.array([0, 3, 3, 10], dtype=np.int32)
+    np.testing.assert_array_equal(convert.widen_indptr(small, 10), small.astype(np.int64))
