@@ -67,7 +67,7 @@ def cpu_baseline(d, f, lam, solver, target_s=16.0):
             update = np.zeros((rows, f), np.float32)
             t = pyoracle.time_half_iteration(ptr[:rows + 1], idx[:nn], val[:nn], gathers[side], update, f, lam,
                                              solver=solver)
-            out[side] = (rows, nn, t)
+            out[side] = (rows, nn, t, update)
             tot_nnz += nn
             tot_t += t
         return out, tot_nnz, tot_t
@@ -75,7 +75,20 @@ def cpu_baseline(d, f, lam, solver, target_s=16.0):
     _, pn, pt = run(1.0 / 64)
     frac = min(1.0, max(1.0 / 64, (target_s / max(pt, 1e-6)) / 64))
     out, tot_nnz, tot_t = run(frac)
-    return {
+    oracle_out = {"gathers": gathers, "x": out["x"][3], "theta": out["theta"][3]}
+    # fp64 evaluation of the same half-iterations where the fp32 oracle's own rounding matters: the X
+    # side (rows of 10^4..10^5 ratings: a sequential fp32 chain that long is itself 1e-4 off) in full, a
+    # 1/16 row sample of the Theta side.  Not timed into the baseline.
+    t64 = time.time()
+    for side, (ptr, idx, val, _) in sides.items():
+        rows = out[side][0] if side == "x" else max(1, out[side][0] // 16)
+        nn = int(ptr[rows])
+        u64 = np.zeros((rows, f), np.float32)
+        pyoracle.half_iteration(ptr[:rows + 1], idx[:nn], val[:nn], gathers[side], u64, f, lam, solver=solver,
+                                dtype=np.float64)
+        oracle_out[side + "64"] = u64
+    oracle_out["fp64_seconds"] = time.time() - t64
+    return oracle_out, {
         "value": tot_nnz / tot_t,
         "unit": "ratings/s",
         "cores": pyoracle.num_threads(),
@@ -85,6 +98,45 @@ def cpu_baseline(d, f, lam, solver, target_s=16.0):
                    f"{out['x'][2]:.2f} s) and the first {out['theta'][0]} Theta rows ({out['theta'][1]} ratings, "
                    f"{out['theta'][2]:.2f} s) of the same synthetic matrix ({100 * frac:.0f} % of its ratings per side)"),
     }
+
+
+def parity_at_scale(r, f, lam, solver, cg_iters, oracle_out, dev):
+    """the oracle half-iterations the cpu_baseline leg has just computed (same
+    matrix, same gather factors, zero warm start) against the HIP half-iterations from the SAME
+    factors -- at BASELINE scale: rows of 10^5 ratings cut into dozens of chunks, the reduce kernel's
+    slot order, 64-bit gather addresses.  Outside the timed region."""
+    from cumf_als_amd import als
+
+    eng = als.ALSEngine(r, f, lam, solver=solver, cg_iters=cg_iters)
+    out = {"solver": solver, "gram_mode": als.get_gram_mode()}
+    for side, gather_attr, step, plans, ptr in (("x", "thetaT", eng.update_x, eng.x_plans, r.csr_indptr),
+                                                ("theta", "XT", eng.update_theta, eng.t_plans, r.csc_indptr)):
+        ref = oracle_out[side]
+        rows = ref.shape[0]
+        getattr(eng, gather_attr).copy_(torch.from_numpy(oracle_out["gathers"][side]))
+        upd = eng.XT if side == "x" else eng.thetaT
+        upd.zero_()
+        step()
+        torch.cuda.synchronize()
+        got = upd[:rows].cpu().numpy()
+        fin = np.isfinite(ref)  # rows without ratings are NaN in both (cg.cu:128)
+        lens = np.diff(ptr.cpu().numpy()[:rows + 1].astype(np.int64))
+        chunk = plans[0].chunk
+        out[f"{side}_side_max_rel"] = float(np.abs(got[fin] - ref[fin]).max() / np.abs(ref[fin]).max())
+        # the same rows evaluated in fp64 by the oracle: the HIP path and the fp32 oracle each against it
+        r64 = oracle_out[side + "64"]
+        n64 = r64.shape[0]
+        f64 = np.isfinite(r64)
+        scale = np.abs(r64[f64]).max()
+        out[f"{side}_side_rows_fp64"] = int(n64)
+        out[f"{side}_side_hip_vs_fp64_max_rel"] = float(np.abs(got[:n64][f64] - r64[f64]).max() / scale)
+        out[f"{side}_side_oracle32_vs_fp64_max_rel"] = float(np.abs(ref[:n64][f64] - r64[f64]).max() / scale)
+        out[f"{side}_side_nan_pattern_equal"] = bool(np.array_equal(np.isnan(got), np.isnan(ref)))
+        out[f"{side}_rows_compared"] = int(rows)
+        out[f"{side}_rows_chunked"] = int((lens > chunk).sum())
+        out[f"{side}_worst_row_len"] = int(lens.max())
+        out[f"{side}_max_chunks_per_row"] = int(-(-int(lens.max()) // chunk))
+    return out
 
 
 def measured_traffic():
@@ -262,27 +314,53 @@ def main() -> int:
         avg_ms = (sum(x_ms) + sum(t_ms)) / (len(x_ms) + len(t_ms))
         avg_bytes = 0.5 * (bx + bt)
         achieved = avg_bytes / (avg_ms * 1e-3) / 1e9
+        mode = als.get_gram_mode()
+        wave = mode == "auto" and not cg and f <= 111
+        kernel = (f"cumf::als_wave_kernel<{f // 16 + 1}, LU, {100 if f == 100 else 0}>" if wave
+                  else f"cumf::als_item_kernel<{f // 16 + 1}, float4, {'CG' if cg else 'LU'}>")
+        traffic = measured_traffic() or {}
+        nb = f // 16 + 1
+        # matrix-pipe work ISSUED per rating: upper-triangular 16x16 tiles x 2*16*16 flops, x6 bf16
+        # products on the split path (als_wave.hip) / x1 on the fp32 MFMA path
+        issued = nb * (nb + 1) / 2 * 512.0 * (6 if wave else 1)
+        pipe_peak = 2500.0 if wave else MFMA_F32_PEAK_TFLOPS
+
+        def side(ms, nbytes, key):
+            ach = nbytes / (ms * 1e-3) / 1e9
+            return {"ms": ms, "alg_bytes": nbytes, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
+                    "traffic": (traffic.get(key) or {}).get("bytes_per_launch"),
+                    "gram_tflops_useful": float(nnz) * f * (f + 1) / (ms * 1e-3) / 1e12,
+                    "matrix_pipe_frac_issued": float(nnz) * issued / (ms * 1e-3) / 1e12 / pipe_peak}
+
+        xs, ts = sum(x_ms) / len(x_ms), sum(t_ms) / len(t_ms)
+        out["dtype"] = "f32 (bf16x3-split products on the bf16 matrix pipe, fp32 accumulate)" if wave else "f32"
         out["roofline"] = {
-            "bound": "hbm", "kernel": "cumf::als_item_kernel<7, float4, LU>" if (f == 100 and not cg) else "cumf::als_item_kernel",
+            "bound": "hbm", "kernel": kernel,
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": (measured_traffic() or {}).get("bytes_per_launch"),
-            "traffic_source": (measured_traffic() or {}).get("source"),
+            "traffic": traffic.get("bytes_per_launch"), "traffic_source": traffic.get("source"),
             "alg_bytes_per_launch": avg_bytes, "avg_launch_ms": avg_ms,
-            "x_side_ms": sum(x_ms) / len(x_ms), "theta_side_ms": sum(t_ms) / len(t_ms),
+            "x_side_ms": xs, "theta_side_ms": ts,
+            "x_side": side(xs, bx, "x_side"), "theta_side": side(ts, bt, "theta_side"),
             "reduce_kernel_ms_x_side": sum(red_ms[0::2]) / len(red_ms[0::2]),
+            "gram_mode": mode,
             "gram_flops_per_launch": float(nnz) * f * (f + 1),
             "gram_tflops": float(nnz) * f * (f + 1) / (avg_ms * 1e-3) / 1e12,
-            # the kernel is co-limited (25 flop/B vs a ridge of ~19.7): the same launch
-            # against the fp32 MFMA roof (algorithmic flops of the symmetric Gram, FMA = 2)
-            "mfma": {"bound": "mfma", "achieved": float(nnz) * f * (f + 1) / (avg_ms * 1e-3) / 1e12,
-                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": float(nnz) * f * (f + 1) / (avg_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS},
+            # the matrix pipe next to the HBM roof: flops issued (tile padding and, on the split path,
+            # the six bf16 products per fp32 product included) against the pipe's dense peak
+            "mfma": {"bound": "mfma", "pipe": "bf16 (6 products per fp32 product)" if wave else "fp32",
+                     "achieved": float(nnz) * issued / (avg_ms * 1e-3) / 1e12, "peak": pipe_peak, "unit": "TFLOP/s",
+                     "frac": float(nnz) * issued / (avg_ms * 1e-3) / 1e12 / pipe_peak},
+            # what a perfect kernel of this design would take: the larger of the HBM time of the
+            # algorithmic bytes and the matrix-pipe time of the issued flops
+            "floor_ms": {"hbm": avg_bytes / (HBM_PEAK_GBS * 1e9) * 1e3, "matrix_pipe": float(nnz) * issued / (pipe_peak * 1e12) * 1e3},
         }
         tr, te = eng.rmse()
         out["rmse"] = {"train": tr, "test": te, "after_iterations": a.warmup + a.steps + len(x_ms)}
         if not a.no_cpu_baseline:
             d = {k: v for k, v in r.numpy().items() if k.startswith("cs")}
-            out["cpu_baseline"] = cpu_baseline(d, f, lam, a.solver)
+            oracle_out, out["cpu_baseline"] = cpu_baseline(d, f, lam, a.solver)
+            del eng
+            out["parity_at_scale"] = parity_at_scale(r, f, lam, a.solver, a.cg_iters, oracle_out, dev)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
