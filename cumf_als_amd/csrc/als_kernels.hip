@@ -1530,7 +1530,7 @@ hipError_t wave_item_launch(const KernelArgs& a, int mode, long n_items, hipStre
 #define CUMF_DECLARE_WAVE(N) \
   template <>                \
   hipError_t wave_item_launch<N>(const KernelArgs& a, int mode, long n_items, hipStream_t stream);
-CUMF_DECLARE_WAVE(1) CUMF_DECLARE_WAVE(2) CUMF_DECLARE_WAVE(3) CUMF_DECLARE_WAVE(4) CUMF_DECLARE_WAVE(5)
+CUMF_DECLARE_WAVE(2) CUMF_DECLARE_WAVE(3) CUMF_DECLARE_WAVE(4) CUMF_DECLARE_WAVE(5)
 CUMF_DECLARE_WAVE(6) CUMF_DECLARE_WAVE(7)
 
 static int g_gram_mode = -1;
@@ -1543,7 +1543,11 @@ int gram_mode() {
   return g_gram_mode;
 }
 bool wave_path_available(int f, int mode) {
-  return gram_mode() != kGramExact && nb_for_f(f) <= kMaxWaveNB && (mode == kModeLU || mode == kModeMaterialize);
+  // NB = 1 (f <= 14: one tile, a 32-rating MFMA K and one wave per row are all overhead) stays on the
+  // workgroup kernels: measured 0.56 vs 3.4 ms per iteration at f = 10, while f = 20 .. 48 is 1.4-1.7x
+  // faster on the wave kernels
+  return gram_mode() != kGramExact && nb_for_f(f) >= 2 && nb_for_f(f) <= kMaxWaveNB &&
+         (mode == kModeLU || mode == kModeMaterialize);
 }
 
 hipError_t launch_half_iteration(const KernelArgs& a, int mode, long n_items, long n_mrows, hipStream_t stream) {
@@ -1560,7 +1564,7 @@ hipError_t launch_half_iteration(const KernelArgs& a, int mode, long n_items, lo
     if (g_timing) (void)hipEventRecord(g_ev[1], stream);          \
     e = slice_reduce_only<N>(a, mode, n_mrows, stream);           \
     break;
-      CUMF_WAVE(1) CUMF_WAVE(2) CUMF_WAVE(3) CUMF_WAVE(4) CUMF_WAVE(5) CUMF_WAVE(6) CUMF_WAVE(7)
+      CUMF_WAVE(2) CUMF_WAVE(3) CUMF_WAVE(4) CUMF_WAVE(5) CUMF_WAVE(6) CUMF_WAVE(7)
 #undef CUMF_WAVE
       default: return hipErrorInvalidValue;
     }

@@ -119,7 +119,7 @@ int cumf_sse(const float* val, const int* row, const int* col, const float* thet
  * Arithmetic of the Gram pass (the reference chooses its variants at compile time too:
  * `#define CUMF_USE_HALF` / CUMF_TT_FP16, als.cu:25-33).
  *   CUMF_GRAM_AUTO  (default) fp32 evaluated on the bf16 matrix pipe where a kernel for it exists
- *                   (LU solver and the materialising pass, f <= 111): every gathered fp32 value is
+ *                   (LU solver and the materialising pass, 16 <= f <= 111): every gathered fp32 value is
  *                   split EXACTLY into three bf16 terms and each product is formed from six bf16
  *                   products with fp32 accumulation; the dropped terms are < 2^-23 of a product.
  *                   fp32-class error against an fp64 Gram, not bit-identical to get_hermitian's

@@ -58,7 +58,7 @@ def test_gram_whole_rows_bit_exact(oracle, alslib, f):
     np.testing.assert_array_equal(rhs.cpu().numpy(), b_o)
 
 
-@pytest.mark.parametrize("f", [10, 20, 64, 100, 110])
+@pytest.mark.parametrize("f", [20, 30, 64, 100, 110])
 def test_split_gram_error_class(oracle, alslib, f):
     """Default Gram arithmetic (als_wave.hip): every fp32 value split exactly into three bf16
     terms, products hh + hm + mh + mm + hl + lh on v_mfma_f32_16x16x32_bf16, fp32 accumulation.

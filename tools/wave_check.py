@@ -22,7 +22,7 @@ def factors(rows, f, seed):
 def main():
     pyoracle.build()
     bad = 0
-    for f in (10, 20, 64, 100, 110):
+    for f in (20, 30, 64, 100, 110):
         r = datagen.synth_ratings(96, 400, 9000, 300, seed=f, row_alpha=1.2)
         d = r.numpy()
         theta = factors(r.n, f, 1)
