@@ -451,159 +451,6 @@ __device__ __forceinline__ void back_substitute_tiles(const f32x4 (&acc)[NB * (N
 }
 
 // ----------------------------------------------------------------------------------
-// The same elimination, software-pipelined across panels (compile-time f only).  In the plain
-// form a panel is [pivot chain + row forming: ~100 dependent VALU / DS instructions, matrix pipe
-// idle] followed by [up to 28 back-to-back MFMAs: the wave sits at the pipe for 32 cycles each and
-// issues nothing else] -- 54 000 cycles per system where the critical path is ~10 000.  Here the
-// update of panel P first issues the tiles of the block row that holds panel P + 1 (group A), then
-// the prolog of panel P + 1 (broadcasts, pivot chain, row forming -> ub / la of the other buffer) is
-// laid between the remaining MFMAs of panel P (group B) by sched_group_barrier.
-// ----------------------------------------------------------------------------------
-template <int NB, int FC>
-struct LuPipe {
-  static constexpr int NT = NB * (NB + 1) / 2;
-  static constexpr int NP = (FC + 3) / 4;
-  float ub[2][NB];  // eliminated panel row of this lane group per feature block
-  float la[2][NB];  // -ub / u_kk (A operand of tile row I), masked in the panel's own block row
-  const int c, kk, lane;
-  const bool k1, k2, k3;
-  const float e1c, e2c, e3c;
-  float* rdiag;
-  f32x4 (&acc)[NT];
-
-  __device__ __forceinline__ LuPipe(f32x4 (&a)[NT], float* rd, int ln)
-      : c(ln & 15), kk((ln >> 4) & 3), lane(ln), k1(kk == 1), k2(kk == 2), k3(kk == 3),
-        e1c(k1 ? 1.0f : 0.f), e2c(k2 ? 1.0f : 0.f), e3c(k3 ? 1.0f : 0.f), rdiag(rd), acc(a) {}
-
-  static __device__ __forceinline__ float sel(bool p, float a, float b) { return p ? a : b; }
-  static __device__ __forceinline__ float rl(float v, int l) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-  }
-  static __device__ __forceinline__ float bperm(int addr, float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
-  }
-
-  // broadcasts + pivot chain + row forming of panel P into buffer P & 1 (steps 1, 2, 4 of lu_wave)
-  template <int P>
-  __device__ __forceinline__ void prolog() {
-    constexpr int Ip = P / 4, q = P % 4, p0 = 4 * P, SD = tile_of<NB>(Ip, Ip), l0 = 20 * q, buf = P & 1;
-    const int src = 4 * (16 * q + c);
-    float R[NB][4];
-#if !(CUMF_WAVE_VARIANT & 16)
-    static_for<NB>([&](auto bc) {
-      constexpr int b = decltype(bc)::value;
-      if constexpr (b >= Ip) {
-        constexpr int t = tile_of<NB>(Ip, b);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) R[b][r] = bperm(src, acc[t][r]);
-      }
-    });
-#endif
-    constexpr bool v1 = p0 + 1 < FC, v2 = p0 + 2 < FC, v3 = p0 + 3 < FC;
-    const bool vk = p0 + kk < FC;
-    float P00 = rl(acc[SD][0], l0), P01 = rl(acc[SD][0], l0 + 1), P02 = rl(acc[SD][0], l0 + 2),
-          P03 = rl(acc[SD][0], l0 + 3);
-    float P11 = rl(acc[SD][1], l0 + 1), P12 = rl(acc[SD][1], l0 + 2), P13 = rl(acc[SD][1], l0 + 3);
-    float P22 = rl(acc[SD][2], l0 + 2), P23 = rl(acc[SD][2], l0 + 3);
-    float P33 = rl(acc[SD][3], l0 + 3);
-    auto recip = [](float d) { return __builtin_amdgcn_rcpf(d); };
-    const float rp0 = recip(P00);
-    const float m10 = -P01 * rp0, m20 = -P02 * rp0, m30 = -P03 * rp0;
-    P11 = fmaf(m10, P01, P11);
-    P12 = fmaf(m10, P02, P12);
-    P13 = fmaf(m10, P03, P13);
-    P22 = fmaf(m20, P02, P22);
-    P23 = fmaf(m20, P03, P23);
-    P33 = fmaf(m30, P03, P33);
-    const float rp1 = recip(v1 ? P11 : 1.0f);
-    const float m21 = -P12 * rp1, m31 = -P13 * rp1;
-    P22 = fmaf(m21, P12, P22);
-    P23 = fmaf(m21, P13, P23);
-    P33 = fmaf(m31, P13, P33);
-    const float rp2 = recip(v2 ? P22 : 1.0f);
-    const float m32 = -P23 * rp2;
-    P33 = fmaf(m32, P23, P33);
-    const float rp3 = recip(v3 ? P33 : 1.0f);
-    const float e20 = fmaf(m21, m10, m20);
-    const float e31 = fmaf(m32, m21, m31);
-    const float e30 = fmaf(m32, e20, fmaf(m31, m10, m30));
-    const float rpk = sel(k3, rp3, sel(k2, rp2, sel(k1, rp1, rp0)));
-    const float e0 = sel(k3, e30, sel(k2, e20, sel(k1, m10, 1.0f)));
-    const float e1 = sel(k3, e31, sel(k2, m21, e1c));
-    const float e2 = sel(k3, m32, e2c);
-    const float nrp = sel(vk, -rpk, 0.f);
-    // every lane stores (the lanes that do not hold a reciprocal into a dummy line): no exec-mask
-    // branch, the whole elimination stays one basic block for the scheduler
-    float* rd = (c == 4 && vk) ? rdiag + p0 + kk : rdiag + ((FC + 3) & ~3) + 16 + lane;
-    *rd = rpk;
-    static_for<NB>([&](auto bc) {
-      constexpr int b = decltype(bc)::value;
-      if constexpr (b >= Ip) {
-#if CUMF_WAVE_VARIANT & 16
-        {
-          constexpr int t = tile_of<NB>(Ip, b);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) R[b][r] = bperm(src, acc[t][r]);
-        }
-#endif
-        const float u = fmaf(e3c, R[b][3], fmaf(e2, R[b][2], fmaf(e1, R[b][1], e0 * R[b][0])));
-        ub[buf][b] = u;
-        float l = u * nrp;
-        if constexpr (b == Ip) l = sel(c > 4 * q + kk, l, 0.f);  // rows at or above the pivot stay
-        la[buf][b] = l;
-      }
-    });
-  }
-
-  template <int P, int I, int J>
-  __device__ __forceinline__ void update_tile() {
-    constexpr int t = tile_of<NB>(I, J), buf = P & 1;
-    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(la[buf][I], ub[buf][J], acc[t], 0, 0, 0);
-  }
-
-  __device__ __forceinline__ void run() {
-    prolog<0>();
-    static_for<NP>([&](auto pc) {
-      constexpr int P = decltype(pc)::value;
-      constexpr int Ip = P / 4;
-      constexpr bool has_next = P + 1 < NP;
-      constexpr int In = has_next ? (P + 1) / 4 : NB;  // block row of the next panel
-      // group A: the block row of the next panel
-      static_for<NB>([&](auto jc) {
-        constexpr int J = decltype(jc)::value;
-        if constexpr (has_next && J >= In) update_tile<P, In, J>();
-      });
-      if constexpr (has_next) prolog<P + 1>();
-      // group B: the other live tiles
-      static_for<NB>([&](auto ic) {
-        constexpr int I = decltype(ic)::value;
-        if constexpr (I >= Ip && I != In) {
-          static_for<NB>([&](auto jc) {
-            constexpr int J = decltype(jc)::value;
-            if constexpr (J >= I) update_tile<P, I, J>();
-          });
-        }
-      });
-      // schedule: group A up front, then the prolog spread over the MFMAs of group B
-      constexpr int nA = has_next ? NB - In : 0;
-      constexpr int live = (NB - Ip) * (NB - Ip + 1) / 2;
-      constexpr int nB = live - nA;
-      constexpr int nbk = has_next ? NB - In : 0;
-      constexpr int n_other = has_next ? 62 + 10 * nbk : 0;  // readlanes + chain + selects + per block: 4 DS + 6 VALU
-      if constexpr (nA > 0) __builtin_amdgcn_sched_group_barrier(0x008, nA, 0);
-      if constexpr (nB > 0 && n_other > 0) {
-        constexpr int per = (n_other + nB - 1) / nB;
-        static_for<nB>([&](auto) {
-          __builtin_amdgcn_sched_group_barrier(0x086, per, 0);  // VALU | SALU | DS
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        });
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    });
-  }
-};
-
-// ----------------------------------------------------------------------------------
 // Unpivoted Gaussian elimination of [A | b] on the accumulators of ONE wave + back
 // substitution: the content of cublasSgetrfBatched(PivotArray = NULL) + cublasSgetrsBatched
 // (als.cu:77,98 / 146,166).  Panel of four pivots p0 .. p0 + 3 (block row Ip, lane group q):
@@ -639,17 +486,10 @@ __device__ __forceinline__ void lu_wave(f32x4 (&acc)[NB * (NB + 1) / 2], float* 
   float* zpad = rdiag + ((f + 3) & ~3);
   if (lane < 16) zpad[lane] = 0.f;
 
-  auto rl = [](float v, int l) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-  };
   auto bperm = [](int addr, float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
   };
 
-  if constexpr (FC != 0 && !(CUMF_WAVE_VARIANT & 4)) {
-    LuPipe<NB, FC> pipe(acc, rdiag, lane);
-    pipe.run();
-  } else {
   static_for<NB>([&](auto ipc) {
     constexpr int Ip = decltype(ipc)::value;
     constexpr int SD = tile_of<NB>(Ip, Ip);
@@ -673,11 +513,16 @@ __device__ __forceinline__ void lu_wave(f32x4 (&acc)[NB * (NB + 1) / 2], float* 
         constexpr int l0 = 20 * q;
         const bool v1 = p0 + 1 < f, v2 = p0 + 2 < f, v3 = p0 + 3 < f;
         const bool vk = p0 + kk < f;  // this lane group's pivot exists (short last panel otherwise)
-        float P00 = rl(acc[SD][0], l0), P01 = rl(acc[SD][0], l0 + 1), P02 = rl(acc[SD][0], l0 + 2),
-              P03 = rl(acc[SD][0], l0 + 3);
-        float P11 = rl(acc[SD][1], l0 + 1), P12 = rl(acc[SD][1], l0 + 2), P13 = rl(acc[SD][1], l0 + 3);
-        float P22 = rl(acc[SD][2], l0 + 2), P23 = rl(acc[SD][2], l0 + 3);
-        float P33 = rl(acc[SD][3], l0 + 3);
+        // v_readlane: measured faster than a wave-uniform ds_bpermute broadcast (Theta side 12.8 vs 13.3 ms):
+        // a DS instruction holds the wave's issue slot twice as long as a VALU one
+        auto bc = [&](float v, int l) {
+          return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+        };
+        float P00 = bc(acc[SD][0], l0), P01 = bc(acc[SD][0], l0 + 1), P02 = bc(acc[SD][0], l0 + 2),
+              P03 = bc(acc[SD][0], l0 + 3);
+        float P11 = bc(acc[SD][1], l0 + 1), P12 = bc(acc[SD][1], l0 + 2), P13 = bc(acc[SD][1], l0 + 3);
+        float P22 = bc(acc[SD][2], l0 + 2), P23 = bc(acc[SD][2], l0 + 3);
+        float P33 = bc(acc[SD][3], l0 + 3);
         auto recip = [](float d) { return __builtin_amdgcn_rcpf(d); };
         const float rp0 = recip(P00);
         const float m10 = -P01 * rp0, m20 = -P02 * rp0, m30 = -P03 * rp0;
@@ -739,7 +584,6 @@ __device__ __forceinline__ void lu_wave(f32x4 (&acc)[NB * (NB + 1) / 2], float* 
       }
     });
   });
-  }
   __syncthreads();  // one wave: orders the rdiag writes before the reads below
   back_substitute_tiles<NB, (16 * NB + 63) / 64>(acc, T, rdiag, zpad, f, x_global, lane);
 }
