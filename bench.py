@@ -252,10 +252,15 @@ def main() -> int:
 
         from cumf_als_amd import dist as cdist
 
-        d = r.numpy()
-        mat = cdist.HostMatrix(m, n, d["csr_indptr"], d["csr_indices"], d["csr_data"], d["csc_indptr"],
-                               d["csc_indices"], d["csc_data"])
-        eng = cdist.DistALS(mat, f, lam, cdist.HipOps(dev), solver=a.solver, cg_iters=a.cg_iters, scheme=a.scheme)
+        if a.scheme == "gather":
+            # every rank generates the same matrix on its own GPU (same seed) and keeps zero-copy views
+            # of its row / column slabs: nothing travels through host memory
+            eng = cdist.DistALS.from_device_ratings(r, f, lam, cdist.HipOps(dev), solver=a.solver, cg_iters=a.cg_iters)
+        else:
+            d = r.numpy()
+            mat = cdist.HostMatrix(m, n, d["csr_indptr"], d["csr_indices"], d["csr_data"], d["csc_indptr"],
+                                   d["csc_indices"], d["csc_data"])
+            eng = cdist.DistALS(mat, f, lam, cdist.HipOps(dev), solver=a.solver, cg_iters=a.cg_iters, scheme=a.scheme)
         eng.init_factors(theta0)
 
         def step(timed):

@@ -203,6 +203,30 @@ def lu_solve(A, b, x=None):
     return x
 
 
+def pack_upper(full, packed=None):
+    """full[batch, f, f] (symmetric) -> packed[batch, f(f+1)/2] upper triangles (cumf_pack_upper)."""
+    import torch
+
+    lib = _libmod.load()
+    batch, f = full.shape[0], full.shape[-1]
+    if packed is None:
+        packed = torch.empty((batch, f * (f + 1) // 2), dtype=torch.float32, device=full.device)
+    _libmod.check(lib.cumf_pack_upper(_dp(full, torch.float32), _dp(packed, torch.float32), batch, f, _stream()),
+                  "cumf_pack_upper")
+    return packed
+
+
+def unpack_upper(packed, full):
+    """packed[batch, f(f+1)/2] -> full[batch, f, f], both triangles (cumf_unpack_upper)."""
+    import torch
+
+    lib = _libmod.load()
+    batch, f = full.shape[0], full.shape[-1]
+    _libmod.check(lib.cumf_unpack_upper(_dp(packed, torch.float32), _dp(full, torch.float32), batch, f, _stream()),
+                  "cumf_unpack_upper")
+    return full
+
+
 def sse(val, row, col, thetaT, XT, count: int | None = None, surpass_nan: bool = False, out=None):
     """Sum of squared errors over the first `count` ratings -> 1-element fp64 tensor (cumf_sse)."""
     import torch

@@ -84,6 +84,9 @@ enum { kGramAuto = 0, kGramExact = 1 };
 void set_gram_mode(int mode);
 int gram_mode();
 bool wave_path_available(int f, int mode);
+// unpack = 0: full (batch x f x f) -> packed (batch x f(f+1)/2); unpack = 1: `full` is the packed input,
+// `packed` receives the mirrored full matrices
+hipError_t launch_pack_upper(const float* full, float* packed, long batch, int f, int unpack, hipStream_t stream);
 void set_kernel_timing(bool on);
 hipError_t last_kernel_ms(float* item_ms, float* reduce_ms);
 hipError_t launch_sse(const float* val, const int* row, const int* col, const float* thetaT, const float* XT,

@@ -1281,6 +1281,41 @@ __global__ __launch_bounds__(kThreads) void sse_kernel(const float* __restrict__
 }
 
 // ----------------------------------------------------------------------------------
+// Packed upper triangle of a batch of symmetric f x f Grams (row i keeps columns i .. f-1,
+// f (f + 1) / 2 floats per system): the payload of the multi-GPU partial-Gram reduction
+// (hugewiki.cu:2703-2717 moves the full f x f per GPU; half of it is redundant).
+// ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void pack_upper_kernel(const float* __restrict__ full, float* __restrict__ packed,
+                                                              int f) {
+  const size_t sys = blockIdx.x;
+  const float* A = full + sys * (size_t)f * f;
+  float* P = packed + sys * (size_t)(f * (f + 1) / 2);
+  for (int e = threadIdx.x; e < f * f; e += kThreads) {
+    const int i = e / f, j = e - i * f;
+    if (j >= i) P[i * f - i * (i - 1) / 2 + (j - i)] = A[e];
+  }
+}
+__global__ __launch_bounds__(kThreads) void unpack_upper_kernel(const float* __restrict__ packed, float* __restrict__ full,
+                                                                int f) {
+  const size_t sys = blockIdx.x;
+  float* A = full + sys * (size_t)f * f;
+  const float* P = packed + sys * (size_t)(f * (f + 1) / 2);
+  for (int e = threadIdx.x; e < f * f; e += kThreads) {
+    const int i = e / f, j = e - i * f;
+    const int a = i < j ? i : j, b = i < j ? j : i;
+    A[e] = P[a * f - a * (a - 1) / 2 + (b - a)];
+  }
+}
+hipError_t launch_pack_upper(const float* full, float* packed, long batch, int f, int unpack, hipStream_t stream) {
+  if (batch <= 0) return hipSuccess;
+  if (unpack)
+    hipLaunchKernelGGL(unpack_upper_kernel, dim3((unsigned)batch), dim3(kThreads), 0, stream, full, packed, f);
+  else
+    hipLaunchKernelGGL(pack_upper_kernel, dim3((unsigned)batch), dim3(kThreads), 0, stream, full, packed, f);
+  return hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------------
 // Launchers
 // ----------------------------------------------------------------------------------
 

@@ -283,6 +283,15 @@ extern "C" int cumf_lu_solve_batched(const float* A, const float* b, float* x, l
   return 0;
 }
 
+extern "C" int cumf_pack_upper(const float* full, float* packed, long batch, int f, void* stream) {
+  CUMF_HIP_CHECK(launch_pack_upper(full, packed, batch, f, 0, static_cast<hipStream_t>(stream)));
+  return 0;
+}
+extern "C" int cumf_unpack_upper(const float* packed, float* full, long batch, int f, void* stream) {
+  CUMF_HIP_CHECK(launch_pack_upper(packed, full, batch, f, 1, static_cast<hipStream_t>(stream)));
+  return 0;
+}
+
 extern "C" int cumf_sse(const float* val, const int* row, const int* col, const float* thetaT, const float* XT,
                         long count, int f, int surpass_nan, double* sse_out, void* stream) {
   CUMF_HIP_CHECK(launch_sse(val, row, col, thetaT, XT, count, f, surpass_nan, sse_out, static_cast<hipStream_t>(stream)));

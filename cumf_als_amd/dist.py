@@ -115,6 +115,12 @@ class HipOps:
         else:
             self.als.lu_solve(tt, rhs, x)
 
+    def pack_upper(self, full, packed):
+        self.als.pack_upper(full, packed)
+
+    def unpack_upper(self, packed, full):
+        self.als.unpack_upper(packed, full)
+
     def sse(self, val, row, col, thetaT, XT) -> float:
         """sum (r - x_row . theta_col)^2 over the given ratings (als.cu:191-219)."""
         if val.numel() == 0:
@@ -130,39 +136,66 @@ def _needs_host_staging(t: torch.Tensor) -> bool:
     return t.is_cuda and dist.get_backend() != "nccl"
 
 
+class SlabGather:
+    """out[bounds[g]:bounds[g+1]] <- rank g's slab, for all g (row slabs of unequal size), as ONE
+    `all_gather_into_tensor` on slabs padded to the largest one (a single RCCL collective; on the
+    fully connected xGMI mesh every link carries 1/(G-1) of it).  The padded send / receive buffers
+    and the row map from the padded layout back to `out` are built once and reused: a call is one
+    copy into the send buffer, the collective, and one `index_select` (no per-rank Python loop, no
+    allocation)."""
+
+    def __init__(self, bounds, cols: int, dtype, device, group=None):
+        self.group = group
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.world = world
+        self.sizes = [int(bounds[g + 1] - bounds[g]) for g in range(world)]
+        self.mx = max(self.sizes) if self.sizes else 0
+        self.staged = device.type == "cuda" and dist.is_initialized() and dist.get_backend() != "nccl"
+        stage_dev = torch.device("cpu") if self.staged else device
+        self.send = torch.zeros((self.mx, cols), dtype=dtype, device=stage_dev)
+        self.recv = torch.empty((world * self.mx, cols), dtype=dtype, device=stage_dev)
+        idx = np.concatenate([g * self.mx + np.arange(self.sizes[g], dtype=np.int64) for g in range(world)]) \
+            if world else np.zeros(0, np.int64)
+        self.idx = torch.from_numpy(idx).to(stage_dev)
+
+    def __call__(self, out: torch.Tensor, mine: torch.Tensor) -> None:
+        if self.world == 1 and not dist.is_initialized():
+            if out.data_ptr() != mine.data_ptr():
+                out[: mine.shape[0]].copy_(mine)
+            return
+        self.send[: mine.shape[0]].copy_(mine)
+        dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+        if self.staged:
+            out.copy_(self.recv.index_select(0, self.idx))
+        else:
+            torch.index_select(self.recv, 0, self.idx, out=out)
+
+
 def all_gather_rows(out: torch.Tensor, mine: torch.Tensor, bounds, group=None) -> None:
-    """out[bounds[g]:bounds[g+1]] <- rank g's `mine`, for all g (row slabs of unequal size).
-
-    One `all_gather_into_tensor` on slabs padded to the largest slab (a single RCCL
-    collective; on the fully connected xGMI mesh every link carries 1/(G-1) of it)."""
-    world = dist.get_world_size(group)
-    sizes = [int(bounds[g + 1] - bounds[g]) for g in range(world)]
-    mx = max(sizes) if sizes else 0
-    cols = out.shape[1]
-    stage_dev = torch.device("cpu") if _needs_host_staging(out) else out.device
-    send = torch.zeros((mx, cols), dtype=out.dtype, device=stage_dev)
-    send[: mine.shape[0]].copy_(mine)
-    recv = torch.empty((world * mx, cols), dtype=out.dtype, device=stage_dev)
-    dist.all_gather_into_tensor(recv, send, group=group)
-    for g in range(world):
-        out[int(bounds[g]):int(bounds[g + 1])].copy_(recv[g * mx: g * mx + sizes[g]])
+    """One-shot form of `SlabGather` (builds the buffers for this call only)."""
+    SlabGather(bounds, out.shape[1], out.dtype, out.device, group)(out, mine)
 
 
-def reduce_scatter_rows(full: torch.Tensor, group=None) -> torch.Tensor:
-    """Sum `full` ([world * k, ...]) over ranks and return this rank's k rows."""
-    if not dist.is_initialized():
-        return full
-    world = dist.get_world_size(group)
+def reduce_scatter_rows(full: torch.Tensor, group=None, out: torch.Tensor | None = None, async_op: bool = False):
+    """Sum `full` ([world * k, ...]) over ranks; this rank's k rows land in `out` (allocated if None).
+    Returns (out, work): `work` is the RCCL work handle when async_op (its .wait() orders the current
+    stream behind the collective), else None."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
     k = full.shape[0] // world
+    if out is None:
+        out = torch.empty((k,) + tuple(full.shape[1:]), dtype=full.dtype, device=full.device)
+    if not dist.is_initialized():
+        out.copy_(full[:k])
+        return out, None
     if _needs_host_staging(full) or not full.is_cuda:
         # gloo has no reduce_scatter: all_reduce + slice (test path only)
         buf = full.cpu() if full.is_cuda else full.clone()
         dist.all_reduce(buf, group=group)
         r = dist.get_rank(group)
-        return buf[r * k:(r + 1) * k].to(full.device)
-    out = torch.empty((k,) + tuple(full.shape[1:]), dtype=full.dtype, device=full.device)
-    dist.reduce_scatter_tensor(out, full, group=group)
-    return out
+        out.copy_(buf[r * k:(r + 1) * k])
+        return out, None
+    work = dist.reduce_scatter_tensor(out, full, group=group, async_op=async_op)
+    return out, (work if async_op else None)
 
 
 def all_gather_equal(out: torch.Tensor, mine: torch.Tensor, group=None) -> None:
@@ -239,6 +272,64 @@ class DistALS:
                 self.t_batches.append((off, size, ops.plan(cp, f, chunk, off, off + size)))
         else:
             raise ValueError(scheme)
+        self._setup_comm()
+
+    def _setup_comm(self) -> None:
+        """Persistent communication buffers (nothing is allocated or zero-filled
+        per half-iteration)."""
+        dev, f, w = self.thetaT.device, self.f, self.world
+        self._gx = self._gt = None
+        if self.scheme == "gather":
+            self._gx = SlabGather(self.xb, f, torch.float32, dev, self.group)
+            self._gt = SlabGather(self.tb, f, torch.float32, dev, self.group)
+            return
+        # reduce scheme.  Per Theta batch: k = ceil(size / world) systems per rank.  Two sets of
+        # buffers so that the reduce-scatter of batch b runs (RCCL stream) under the Gram pass of
+        # batch b + 1 (compute stream).  Payload = packed upper triangles (f (f + 1) / 2 floats per
+        # system instead of f * f: 0.80 GB instead of 1.59 GB per hugewiki Theta batch at f = 100)
+        # + the RHS (f floats per system) as a second, small collective.
+        self._kmax = max((size + w - 1) // w for (_, size, _) in self.t_batches)
+        self._pk = f * (f + 1) // 2
+        nb = 2 if len(self.t_batches) > 1 else 1
+        self._tt = [torch.empty((w * self._kmax, f, f), dtype=torch.float32, device=dev) for _ in range(nb)]
+        self._rhs = [torch.empty((w * self._kmax, f), dtype=torch.float32, device=dev) for _ in range(nb)]
+        self._tri = [torch.zeros((w * self._kmax, self._pk), dtype=torch.float32, device=dev) for _ in range(nb)]
+        self._mine = [torch.empty((self._kmax, self._pk), dtype=torch.float32, device=dev) for _ in range(nb)]
+        self._mine_rhs = [torch.empty((self._kmax, f), dtype=torch.float32, device=dev) for _ in range(nb)]
+        self._my_tt = torch.empty((self._kmax, f, f), dtype=torch.float32, device=dev)
+        self._my_rhs = torch.empty((self._kmax, f), dtype=torch.float32, device=dev)
+        self._x = torch.zeros((self._kmax, f), dtype=torch.float32, device=dev)
+        self._gathered = torch.empty((w * self._kmax, f), dtype=torch.float32, device=dev)
+
+    @classmethod
+    def from_device_ratings(cls, r, f: int, lam: float, ops, solver="cg", cg_iters: int = 6, group=None,
+                            chunk: int = 0) -> "DistALS":
+        """`gather` scheme from a `datagen.Ratings` that is already on this rank's device: the slabs are
+        zero-copy views of its CSR / CSC arrays (no host round trip of the 1.6 GB matrix; only the two
+        row-pointer arrays, a few MB, go to the host for the plans)."""
+        self = cls.__new__(cls)
+        self.f, self.lam, self.ops = f, float(lam), ops
+        self.solver, self.cg_iters, self.scheme = solver, cg_iters, "gather"
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.m, self.n = r.m, r.n
+        self.theta_batch = 1
+        dev = r.csr_indices.device
+        self.thetaT = torch.zeros((self.n, f), dtype=torch.float32, device=dev)
+        self.XT = torch.zeros((self.m, f), dtype=torch.float32, device=dev)
+        rp = r.csr_indptr.cpu().numpy().astype(np.int64)
+        cp = r.csc_indptr.cpu().numpy().astype(np.int64)
+        self.xb, self.tb = balanced_slabs(rp, self.world), balanced_slabs(cp, self.world)
+        x0, x1 = int(self.xb[self.rank]), int(self.xb[self.rank + 1])
+        t0, t1 = int(self.tb[self.rank]), int(self.tb[self.rank + 1])
+        self.x_rows, self.t_rows = x1 - x0, t1 - t0
+        self.x_plan = ops.plan(rp[x0:x1 + 1] - rp[x0], f, chunk)
+        self.t_plan = ops.plan(cp[t0:t1 + 1] - cp[t0], f, chunk)
+        self.x_colidx, self.x_val = r.csr_indices[rp[x0]:rp[x1]], r.csr_data[rp[x0]:rp[x1]]
+        self.t_colidx, self.t_val = r.csc_indices[cp[t0]:cp[t1]], r.csc_data[cp[t0]:cp[t1]]
+        self._setup_comm()
+        return self
 
     @classmethod
     def from_local_slab(cls, m_total: int, n: int, xb, rowptr_l: torch.Tensor, colidx_l: torch.Tensor,
@@ -269,6 +360,7 @@ class DistALS:
             size = n // theta_batch if b != theta_batch - 1 else n - b * (n // theta_batch)
             off = b * (n // theta_batch)
             self.t_batches.append((off, size, ops.plan(cp, f, chunk, off, off + size)))
+        self._setup_comm()
         return self
 
     # -- factors ---------------------------------------------------------------------------
@@ -287,7 +379,10 @@ class DistALS:
         if self.scheme == "gather":
             return self.XT
         out = torch.empty((self.m, self.f), dtype=torch.float32, device=self.XT.device)
-        all_gather_rows(out, self.XT, self.xb, self.group)
+        if dist.is_initialized():
+            all_gather_rows(out, self.XT, self.xb, self.group)
+        else:
+            out.copy_(self.XT)
         return out
 
     # -- half-iterations -------------------------------------------------------------------
@@ -297,7 +392,7 @@ class DistALS:
             mine = self.XT[x0:x1]
             self.ops.update_fused(self.x_plan, self.x_colidx, self.x_val, self.thetaT, mine, self.lam,
                                   self.solver, self.cg_iters)
-            all_gather_rows(self.XT, mine, self.xb, self.group)
+            self._gx(self.XT, mine)
         else:
             self.ops.update_fused(self.x_plan, self.x_colidx, self.x_val, self.thetaT, self.XT, self.lam,
                                   self.solver, self.cg_iters)
@@ -308,28 +403,50 @@ class DistALS:
             mine = self.thetaT[t0:t1]
             self.ops.update_fused(self.t_plan, self.t_colidx, self.t_val, self.XT, mine, self.lam,
                                   self.solver, self.cg_iters)
-            all_gather_rows(self.thetaT, mine, self.tb, self.group)
+            self._gt(self.thetaT, mine)
             return
-        f, w = self.f, self.world
-        dev = self.XT.device
-        for (off, size, plan) in self.t_batches:
-            ridx, rval = self.lc_rowidx, self.lc_val
+        # reduce scheme (replaces hugewiki.cu:2611-2745).  Pipeline over the Theta batches:
+        #   Gram(b) -> pack -> reduce-scatter(b) [async, RCCL stream]   ||   Gram(b + 1) ...
+        #   wait(b) -> unpack -> solve(b) -> all-gather(b)
+        f, w, pk = self.f, self.world, self._pk
+        pending = None  # (batch index, buffer set, work handle)
+
+        def finish(bi, slot, works):
+            off, size, _ = self.t_batches[bi]
             k = (size + w - 1) // w
-            tt = torch.zeros((w * k, f, f), dtype=torch.float32, device=dev)
-            rhs = torch.zeros((w * k, f), dtype=torch.float32, device=dev)
-            # partial Gram / RHS over this rank's X slab (hugewiki.cu:2668-2679)
-            self.ops.get_hermitian(plan, ridx, rval, self.XT, self.lam, tt[:size], rhs[:size])
-            my_tt = reduce_scatter_rows(tt, self.group)      # replaces hugewiki.cu:2703-2717
-            my_rhs = reduce_scatter_rows(rhs, self.group)    # replaces hugewiki.cu:2719-2730
-            lo = min(self.rank * k, size)
-            hi = min((self.rank + 1) * k, size)
-            x = torch.zeros((k, f), dtype=torch.float32, device=dev)
+            for wk in works:
+                if wk is not None:
+                    wk.wait()
+            lo, hi = min(self.rank * k, size), min((self.rank + 1) * k, size)
+            x = self._x[:k]
             if hi > lo:
+                self.ops.unpack_upper(self._mine[slot][: hi - lo], self._my_tt[: hi - lo])
                 x[: hi - lo].copy_(self.thetaT[off + lo: off + hi])          # CG warm start
-                self.ops.solve(my_tt[: hi - lo], my_rhs[: hi - lo], x[: hi - lo], self.solver, self.cg_iters)
-            gathered = torch.empty((w * k, f), dtype=torch.float32, device=dev)
+                self.ops.solve(self._my_tt[: hi - lo], self._mine_rhs[slot][: hi - lo], x[: hi - lo], self.solver,
+                               self.cg_iters)
+            gathered = self._gathered[: w * k]
             all_gather_equal(gathered, x, self.group)        # replaces hugewiki.cu:2744-2745
             self.thetaT[off: off + size].copy_(gathered[:size])
+
+        overlap = len(self.t_batches) > 1
+        for bi, (off, size, plan) in enumerate(self.t_batches):
+            slot = bi % len(self._tt)
+            k = (size + w - 1) // w
+            tt, rhs, tri = self._tt[slot][: w * k], self._rhs[slot][: w * k], self._tri[slot][: w * k]
+            # partial Gram / RHS over this rank's X slab (hugewiki.cu:2668-2679)
+            self.ops.get_hermitian(plan, self.lc_rowidx, self.lc_val, self.XT, self.lam, tt[:size], rhs[:size])
+            self.ops.pack_upper(tt[:size], tri[:size])
+            if size < w * k:  # the padding systems behind the last rank's share (a few rows, not the buffer)
+                tri[size:].zero_()
+                rhs[size:].zero_()
+            if pending is not None:
+                finish(*pending)
+                pending = None
+            _, w1 = reduce_scatter_rows(tri, self.group, out=self._mine[slot][:k], async_op=overlap)   # hugewiki.cu:2703-2717
+            _, w2 = reduce_scatter_rows(rhs, self.group, out=self._mine_rhs[slot][:k], async_op=overlap)  # hugewiki.cu:2719-2730
+            pending = (bi, slot, (w1, w2))
+        if pending is not None:
+            finish(*pending)
 
     # -- RMSE (hugewiki.cu:2750-2862: per-GPU SSE over its slab, summed) -------------------------
     def slab_sse(self, val: torch.Tensor, row_local: torch.Tensor, col: torch.Tensor) -> float:

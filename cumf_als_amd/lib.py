@@ -20,7 +20,7 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 C_SYMBOLS = [
     "cumf_doALS", "cumf_doALS_ex", "cumf_plan_create", "cumf_plan_destroy", "cumf_plan_info",
     "cumf_als_update_fused", "cumf_get_hermitian", "cumf_cg_solve_batched", "cumf_lu_solve_batched",
-    "cumf_sse", "cumf_set_gram_mode", "cumf_get_gram_mode", "cumf_check_gather_table", "cumf_set_kernel_timing", "cumf_last_kernel_ms", "cumf_rand_init", "cumf_als_version", "cumf_als_arch",
+    "cumf_pack_upper", "cumf_unpack_upper", "cumf_sse", "cumf_set_gram_mode", "cumf_get_gram_mode", "cumf_check_gather_table", "cumf_set_kernel_timing", "cumf_last_kernel_ms", "cumf_rand_init", "cumf_als_version", "cumf_als_arch",
 ]
 # C++-linkage drop-in symbols (include/als.h, include/cg.h) under the reference's mangled names
 CXX_SYMBOLS = [
@@ -71,6 +71,10 @@ def load():
     lib.cumf_lu_solve_batched.argtypes = [fp, fp, fp, C.c_long, C.c_int, vp]
     lib.cumf_sse.restype = C.c_int
     lib.cumf_sse.argtypes = [fp, ip, ip, fp, fp, C.c_long, C.c_int, C.c_int, vp, vp]
+    lib.cumf_pack_upper.restype = C.c_int
+    lib.cumf_pack_upper.argtypes = [fp, fp, C.c_long, C.c_int, vp]
+    lib.cumf_unpack_upper.restype = C.c_int
+    lib.cumf_unpack_upper.argtypes = [fp, fp, C.c_long, C.c_int, vp]
     lib.cumf_set_gram_mode.restype = C.c_int
     lib.cumf_set_gram_mode.argtypes = [C.c_int]
     lib.cumf_get_gram_mode.restype = C.c_int

@@ -108,6 +108,14 @@ int cumf_cg_solve_batched(const float* A, float* x, const float* b, long batch, 
 int cumf_lu_solve_batched(const float* A, const float* b, float* x, long batch, int f, void* stream);
 
 /*
+ * Packed upper triangle of a batch of symmetric Grams: row i keeps columns i .. f-1, f (f + 1) / 2
+ * floats per system.  It is what the multi-GPU Theta phase sums across GPUs: the reference copies and
+ * adds the full f x f per GPU (hugewiki.cu:2703-2717), half of which is redundant.  DEVICE pointers.
+ */
+int cumf_pack_upper(const float* full, float* packed, long batch, int f, void* stream);
+int cumf_unpack_upper(const float* packed, float* full, long batch, int f, void* stream);
+
+/*
  * Sum of squared errors over `count` ratings (RMSE kernel + cublasSasum,
  * als.cu:191-219, 979-991, 1006-1019): sse_out is one DEVICE double.
  * surpass_nan reproduces `#define SURPASS_NAN` (als.cu:201-211).

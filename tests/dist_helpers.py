@@ -50,6 +50,19 @@ class OracleOps:
         x.copy_(torch.from_numpy(np.ascontiguousarray(out, np.float32)))
 
 
+    def pack_upper(self, full, packed):
+        f = full.shape[-1]
+        iu = np.triu_indices(f)
+        packed.copy_(torch.from_numpy(np.ascontiguousarray(full.numpy()[:, iu[0], iu[1]])))
+
+    def unpack_upper(self, packed, full):
+        f = full.shape[-1]
+        iu = np.triu_indices(f)
+        out = np.zeros((packed.shape[0], f, f), np.float32)
+        out[:, iu[0], iu[1]] = packed.numpy()
+        out[:, iu[1], iu[0]] = packed.numpy()
+        full.copy_(torch.from_numpy(out))
+
     def sse(self, val, row, col, thetaT, XT):
         if val.numel() == 0:
             return 0.0

@@ -91,3 +91,87 @@ def test_hugewiki_runner_single_gpu(oracle, alslib, tmp_path):
     eng, log = hugewiki.run(str(tmp_path / "s"), n, f, lam, iters, solver="lu", quiet=True)
     assert np.abs(np.array(log) - np.asarray(log_o)).max() <= 1e-4, (log, log_o)
     assert np.abs(eng.thetaT.cpu().numpy() - th0.reshape(n, f)).max() <= 2e-3 * np.abs(th0).max()
+
+
+def _rccl_worker(port, scheme, solver, d, m, n, f, lam, iters, theta0, q):
+    """One rank, backend "nccl" (= RCCL): the device-side collectives of cumf_als_amd.dist --
+    reduce_scatter_tensor on the packed Gram, all_gather_into_tensor on the factor slabs -- execute
+    for real, which the gloo tests (host staging) never reach."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from cumf_als_amd import dist as cdist
+
+        assert dist.get_backend() == "nccl"
+        if scheme == "gather_device":  # what bench.py --gpus N runs: zero-copy slabs of a device-resident matrix
+            from cumf_als_amd import datagen
+
+            r = datagen.Ratings(m=m, n=n, **{k: torch.from_numpy(v).cuda() for k, v in d.items()})
+            eng = cdist.DistALS.from_device_ratings(r, f, lam, cdist.HipOps("cuda:0"), solver=solver, cg_iters=6)
+        else:
+            mat = cdist.HostMatrix(m, n, d["csr_indptr"], d["csr_indices"], d["csr_data"], d["csc_indptr"],
+                                   d["csc_indices"], d["csc_data"])
+            eng = cdist.DistALS(mat, f, lam, cdist.HipOps("cuda:0"), solver=solver, cg_iters=6, scheme=scheme,
+                                theta_batch=3)
+        eng.init_factors(theta0)
+        eng.iterate(iters)
+        torch.cuda.synchronize()
+        q.put((eng.thetaT.cpu().numpy().copy(), eng.full_XT().cpu().numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scheme,solver", [("reduce", "lu"), ("reduce", "cg"), ("gather", "lu"), ("gather_device", "lu")])
+def test_rccl_backend_world1(oracle, alslib, scheme, solver):
+    """the RCCL branches of dist.py (device tensors, no host staging, async
+    reduce-scatter overlapped with the next Theta batch) run on the GPU box with world_size 1."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    import torch.multiprocessing as mp
+
+    from cumf_als_amd import datagen
+    from tests.test_dist_cpu import _free_port
+
+    m, n, f, lam, iters = 120, 90, 20, 0.05, 2
+    r = datagen.synth_ratings(m, n, 6000, 600, seed=12, row_alpha=1.1)
+    d = r.numpy()
+    theta0 = (0.2 * np.random.RandomState(0).random_sample((n, f))).astype(np.float32)
+    th_ref, x_ref = theta0.copy(), np.zeros((m, f), np.float32)
+    oracle.do_als(d, th_ref, x_ref, m, n, f, lam, iters, solver=solver)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), scheme, solver, d, m, n, f, lam, iters, theta0, q))
+    p.start()
+    th, x = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    tol = 2e-4 if solver == "lu" else 3e-3
+    assert np.abs(th - th_ref).max() <= tol * np.abs(th_ref).max()
+    assert np.abs(x - x_ref).max() <= tol * np.abs(x_ref).max()
+
+
+def test_pack_unpack_upper(alslib):
+    """cumf_pack_upper / cumf_unpack_upper: the packed upper triangle that the multi-GPU Theta phase
+    reduce-scatters (half the bytes of hugewiki.cu:2703-2717's full f x f copies)."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    from cumf_als_amd import als
+
+    for f in (10, 64, 100, 200):
+        a = torch.randn(37, f, f, device="cuda")
+        a = a + a.transpose(1, 2)
+        packed = als.pack_upper(a)
+        iu = torch.triu_indices(f, f)
+        assert torch.equal(packed.cpu(), a[:, iu[0], iu[1]].cpu())
+        back = torch.zeros_like(a)
+        als.unpack_upper(packed, back)
+        assert torch.equal(back, a)
