@@ -38,7 +38,7 @@ def _hostptr(a: np.ndarray, dtype) -> C.c_void_p:
 def do_als(csrrow, csrcol, csrval, cscrow, csccol, cscval, coorow, coorowtest, coocoltest, coovaltest,
            m, n, f, nnz, nnz_test, lambda_, iters, xbatch, thetabatch, deviceid=0, *,
            thetat_init=None, xt_init=None, solver="cg", cg_iters=6, fused=True,
-           exact_test_grid=False, surpass_nan=False, quiet=True, return_log=False):
+           exact_test_grid=False, surpass_nan=False, quiet=True, return_log=False, tt_fp16=False):
     """`DoAls` (als_tf.cc): run `iters` ALS iterations on device `deviceid`.
 
     Argument names follow the TF op's inputs: csrrow = CSR indptr (m+1), csrcol = CSR
@@ -73,10 +73,12 @@ def do_als(csrrow, csrcol, csrval, cscrow, csccol, cscval, coorow, coorowtest, c
         _hostptr(np.ascontiguousarray(coocoltest, np.int32), np.int32),
         _hostptr(np.ascontiguousarray(coovaltest, np.float32), np.float32),
     ]
+    lib.cumf_set_tt_fp16(int(bool(tt_fp16)))  # CUMF_TT_FP16 (als.cu:25-33): fp16 Gram storage for the CG solver
     rmse = lib.cumf_doALS_ex(*args, int(m), int(n), int(f), int(nnz), int(nnz_test), float(lambda_),
                              int(iters), int(xbatch), int(thetabatch), int(deviceid),
                              _solver_id(solver), int(cg_iters), int(bool(fused)), int(bool(exact_test_grid)),
                              int(bool(surpass_nan)), int(bool(quiet)), _hostptr(log, np.float32))
+    lib.cumf_set_tt_fp16(0)
     if return_log:
         return thetat, xt, float(rmse), log[:iters]
     return thetat, xt, float(rmse)
@@ -159,17 +161,25 @@ def update_fused(plan: Plan, colidx, val, gather, update, lambda_: float, solver
     return update
 
 
-def get_hermitian(plan: Plan, colidx, val, gather, lambda_: float, tt=None, rhs=None, want_rhs=True):
-    """Materialise the Gram batch tt[rows,f,f] (+ rhs[rows,f]) of the plan's rows (cumf_get_hermitian)."""
+def get_hermitian(plan: Plan, colidx, val, gather, lambda_: float, tt=None, rhs=None, want_rhs=True, half=False):
+    """Materialise the Gram batch tt[rows,f,f] (+ rhs[rows,f]) of the plan's rows (cumf_get_hermitian).
+    half=True (or a float16 `tt`): fp16 storage of the Gram, cumf_get_hermitian_fp16 (als.cu:335-441)."""
     import torch
 
     lib = _libmod.load()
     f, rows = plan.f, plan.batch_rows
     _libmod.check(lib.cumf_check_gather_table(gather.shape[0], f, SOLVER_LU, 1), "cumf_check_gather_table")
+    half = half or (tt is not None and tt.dtype == torch.float16)
     if tt is None:
-        tt = torch.empty((rows, f, f), dtype=torch.float32, device=gather.device)
+        tt = torch.empty((rows, f, f), dtype=torch.float16 if half else torch.float32, device=gather.device)
     if rhs is None and want_rhs:
         rhs = torch.empty((rows, f), dtype=torch.float32, device=gather.device)
+    if half:
+        _libmod.check(lib.cumf_get_hermitian_fp16(plan._h, _dp(colidx, torch.int32), _dp(val, torch.float32),
+                                                  _dp(gather, torch.float32), _dp(tt, torch.float16),
+                                                  _dp(rhs, torch.float32), f, float(lambda_), _stream()),
+                      "cumf_get_hermitian_fp16")
+        return tt, rhs
     _libmod.check(lib.cumf_get_hermitian(plan._h, _dp(colidx, torch.int32), _dp(val, torch.float32),
                                          _dp(gather, torch.float32), _dp(tt, torch.float32),
                                          _dp(rhs, torch.float32), f, float(lambda_), _stream()),
@@ -184,6 +194,11 @@ def cg_solve(A, x, b, cg_iters: int = 6):
     lib = _libmod.load()
     f = b.shape[-1]
     batch = b.numel() // f
+    if A.dtype == torch.float16:  # updateXWithCGHost_tt_fp16 (cg.h:32)
+        _libmod.check(lib.cumf_cg_solve_batched_fp16(_dp(A, torch.float16), _dp(x, torch.float32),
+                                                     _dp(b, torch.float32), batch, f, int(cg_iters), _stream()),
+                      "cumf_cg_solve_batched_fp16")
+        return x
     _libmod.check(lib.cumf_cg_solve_batched(_dp(A, torch.float32), _dp(x, torch.float32), _dp(b, torch.float32),
                                             batch, f, int(cg_iters), _stream()), "cumf_cg_solve_batched")
     return x

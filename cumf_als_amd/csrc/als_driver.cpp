@@ -73,7 +73,18 @@ int env_int(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
+int g_tt_fp16 = -1;  // fp16 Gram storage for the CG solver: `#define CUMF_TT_FP16` / CUMF_XX_FP16 (als.cu:25-33)
+
 }  // namespace
+
+extern "C" int cumf_set_tt_fp16(int enable) {
+  g_tt_fp16 = enable != 0;
+  return 0;
+}
+extern "C" int cumf_get_tt_fp16(void) {
+  if (g_tt_fp16 < 0) g_tt_fp16 = env_int("CUMF_ALS_TT_FP16", 0) != 0;
+  return g_tt_fp16;
+}
 
 extern "C" float cumf_doALS_ex(const int* csrRowIndexHostPtr, const int* csrColIndexHostPtr,
                                const float* csrValHostPtr, const int* cscRowIndexHostPtr,
@@ -89,6 +100,10 @@ extern "C" float cumf_doALS_ex(const int* csrRowIndexHostPtr, const int* csrColI
   if (X_BATCH < 1) X_BATCH = 1;
   if (THETA_BATCH < 1) THETA_BATCH = 1;
   if (!cumf::fused_supported(f, solver == CUMF_SOLVER_LU ? cumf::kModeLU : cumf::kModeCG)) fused = 0;  // CG: f <= 128
+  // fp16 storage of the Gram batch (als.cu:779-783, 893-895): the reference's data flow by construction
+  // (Gram batch in device memory + updateXWithCGHost_tt_fp16); CG only, like the reference
+  const int tt_fp16 = cumf_get_tt_fp16() && solver == CUMF_SOLVER_CG;
+  if (tt_fp16) fused = 0;
 
   // both factor tables are gathered from (Theta by the X update, X by the Theta update)
   DRV_CHECK(cumf_check_gather_table(n, f, solver, !fused));
@@ -118,7 +133,7 @@ extern "C" float cumf_doALS_ex(const int* csrRowIndexHostPtr, const int* csrColI
     long maxb = 0;
     for (long s : sx.size) maxb = s > maxb ? s : maxb;
     for (long s : st.size) maxb = s > maxb ? s : maxb;
-    tt = to_device<float>(nullptr, (size_t)maxb * f * f);
+    tt = to_device<float>(nullptr, tt_fp16 ? ((size_t)maxb * f * f + 1) / 2 : (size_t)maxb * f * f);
     rhs = to_device<float>(nullptr, (size_t)maxb * f);
   }
 
@@ -129,8 +144,14 @@ extern "C" float cumf_doALS_ex(const int* csrRowIndexHostPtr, const int* csrColI
         DRV_CHECK(cumf_als_update_fused(s.plans[b], s.d_colidx, s.d_val, gather, update, f, lambda, solver,
                                         cg_iters, nullptr));
       } else {
-        DRV_CHECK(cumf_get_hermitian(s.plans[b], s.d_colidx, s.d_val, gather, tt, rhs, f, lambda, nullptr));
         float* xb = update + (size_t)s.offset[b] * f;
+        if (tt_fp16) {
+          DRV_CHECK(cumf_get_hermitian_fp16(s.plans[b], s.d_colidx, s.d_val, gather, tt, rhs, f, lambda, nullptr));
+          if (!quiet) printf("\tCG solver with fp16.\n");  // als.cu:826,936
+          DRV_CHECK(cumf_cg_solve_batched_fp16(tt, xb, rhs, s.size[b], f, cg_iters, nullptr));
+          continue;
+        }
+        DRV_CHECK(cumf_get_hermitian(s.plans[b], s.d_colidx, s.d_val, gather, tt, rhs, f, lambda, nullptr));
         if (solver == CUMF_SOLVER_CG) {
           if (!quiet) printf("\tCG solver with fp32.\n");
           DRV_CHECK(cumf_cg_solve_batched(tt, xb, rhs, s.size[b], f, cg_iters, nullptr));

@@ -15,7 +15,7 @@ constexpr int kMaxFusedNB = 9;  // f <= 128  ->  NB = f / 16 + 1 <= 9
 constexpr int kMaxF = 207;      // NB <= 13
 constexpr int kMaxWaveNB = 7;   // wave-per-item kernels (als_wave.hip): f <= 111; register budget of one wave
 
-enum { kModeCG = 0, kModeLU = 1, kModeMaterialize = 2, kModeLUExact = 3 };
+enum { kModeCG = 0, kModeLU = 1, kModeMaterialize = 2, kModeLUExact = 3, kModeCGHalf = 4 };  // CGHalf: A stored as fp16
 
 // Feature blocks of 16 including the slot that carries the rating value (RHS).
 __host__ __device__ constexpr int nb_for_f(int f) { return f / 16 + 1; }
@@ -63,8 +63,9 @@ struct KernelArgs {
   const float* gather;
   float* update;
   // materialise outputs
-  float* tt;
+  float* tt;       // f x f Gram per row; holds _Float16 when tt_half (CUMF_TT_FP16 of als.cu:335-441)
   float* rhs;
+  int tt_half;
   long long row_begin;
   int f;
   float lambda;

@@ -313,8 +313,8 @@ __device__ __forceinline__ void tiles_to_lds(const f32x4 (&acc)[Geo<NB>::TPW], f
 
 // Accumulator tile -> row-major f x f Gram in global memory (both triangles,
 // lambda * n on the diagonal: als.cu:545-566) + RHS.
-template <int NB, int W>
-__device__ __forceinline__ void tiles_to_global(const f32x4 (&acc)[Geo<NB>::TPW], float* __restrict__ tt,
+template <int NB, int W, typename T>
+__device__ __forceinline__ void tiles_to_global(const f32x4 (&acc)[Geo<NB>::TPW], T* __restrict__ tt,
                                                 float* __restrict__ rhs, int f, float reg, int lane) {
   constexpr int NT = Geo<NB>::NT, TPW = Geo<NB>::TPW;
   const int c = lane & 15, kk = lane >> 4;
@@ -329,8 +329,8 @@ __device__ __forceinline__ void tiles_to_global(const f32x4 (&acc)[Geo<NB>::TPW]
         float v = acc[s][r];
         if (i < f && j < f) {
           if (i == j) v += reg;
-          tt[(size_t)i * f + j] = v;
-          if (I != J) tt[(size_t)j * f + i] = v;
+          tt[(size_t)i * f + j] = (T)v;  // T = _Float16: round to nearest even, as __float2half_rn (als.h:373-499)
+          if (I != J) tt[(size_t)j * f + i] = (T)v;
         } else if (i < f && j == f && rhs != nullptr) {
           rhs[i] = v;
         }
@@ -927,9 +927,12 @@ __device__ __forceinline__ void dump_row(const f32x4 (&acc)[Geo<NB>::TPW], float
   if constexpr (MODE == kModeMaterialize) {
     // als.cu:547: float temp = (end - start) * lambda;
     const float reg = (float)rowlen * a.lambda;
-    float* tt = a.tt + (size_t)(row - a.row_begin) * f * f;
+    const size_t off = (size_t)(row - a.row_begin) * f * f;
     float* rhs = a.rhs ? a.rhs + (size_t)(row - a.row_begin) * f : nullptr;
-    tiles_to_global<NB, W>(acc, tt, rhs, f, reg, lane);
+    if (a.tt_half)
+      tiles_to_global<NB, W>(acc, reinterpret_cast<_Float16*>(a.tt) + off, rhs, f, reg, lane);
+    else
+      tiles_to_global<NB, W>(acc, a.tt + off, rhs, f, reg, lane);
   } else {
     // G / the tile store aliases the stage buffers (all MFMA reads are done)
     if constexpr (MODE == kModeLU)
@@ -1143,11 +1146,11 @@ __global__ __launch_bounds__(kThreads) void als_reduce_kernel(const KernelArgs a
 // ----------------------------------------------------------------------------------
 template <int NB, int MODE>
 __global__ __launch_bounds__(kThreads) void solve_lds_kernel(const float* __restrict__ A, const float* __restrict__ b,
-                                                             float* __restrict__ x, int f, int cg_iters) {
+                                                             float* __restrict__ x, int f, int cg_iters, int a_half) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
   const size_t sys = blockIdx.x;
-  const float* As = A + sys * (size_t)f * f;
+  const float* As = A + sys * (size_t)f * f;  // (fp32 layout; the fp16 layout is indexed below)
   if constexpr (NB != 0 && MODE == kModeLU) {
     lu_solve_reg<NB>(GlobalLoad<NB>{As, b + sys * f, f}, smem, f, smem + lu_packed_floats(NB), x + sys * f,
                                tid);
@@ -1155,9 +1158,17 @@ __global__ __launch_bounds__(kThreads) void solve_lds_kernel(const float* __rest
   }
   const int ldg = solve_ldg(f, MODE);
   float* G = smem;
-  for (int e = tid; e < f * f; e += kThreads) {
-    const int i = e / f, j = e - i * f;
-    G[i * ldg + j] = As[e];
+  if (a_half) {  // updateXWithCGKernel3 (cg.cu:235-429): A stored as half, arithmetic in fp32
+    const _Float16* Ah = reinterpret_cast<const _Float16*>(A) + sys * (size_t)f * f;
+    for (int e = tid; e < f * f; e += kThreads) {
+      const int i = e / f, j = e - i * f;
+      G[i * ldg + j] = (float)Ah[e];
+    }
+  } else {
+    for (int e = tid; e < f * f; e += kThreads) {
+      const int i = e / f, j = e - i * f;
+      G[i * ldg + j] = As[e];
+    }
   }
   if (tid < f) G[tid * ldg + f] = b[sys * f + tid];
   __syncthreads();
@@ -1172,12 +1183,13 @@ __global__ __launch_bounds__(kThreads) void solve_lds_kernel(const float* __rest
 // LDS-resident system (f > 128).  One workgroup per system, thread t owns row t
 // (blockDim = f rounded up to 64; same shape as cg.cu:36-231, wave64 reductions).
 __global__ void cg_global_kernel(const float* __restrict__ A, float* __restrict__ x, const float* __restrict__ b,
-                                 int f, int cg_iters) {
+                                 int f, int cg_iters, int a_half) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
   float* ps = smem;             // f
   float* red = smem + blockDim.x;  // nwaves
   const float* As = A + (size_t)blockIdx.x * f * f;
+  const _Float16* Ah = reinterpret_cast<const _Float16*>(A) + (size_t)blockIdx.x * f * f;  // a_half (cg.cu:253,289)
   float* xs = x + (size_t)blockIdx.x * f;
   const bool own = tid < f;
 
@@ -1192,8 +1204,12 @@ __global__ void cg_global_kernel(const float* __restrict__ A, float* __restrict_
   };
   auto matvec = [&]() {
     float s = 0.f;
-    if (own)
-      for (int j = 0; j < f; ++j) s = fmaf(As[(size_t)j * f + tid], ps[j], s);
+    if (own) {
+      if (a_half)
+        for (int j = 0; j < f; ++j) s = fmaf((float)Ah[(size_t)j * f + tid], ps[j], s);
+      else
+        for (int j = 0; j < f; ++j) s = fmaf(As[(size_t)j * f + tid], ps[j], s);
+    }
     return s;
   };
 
@@ -1409,7 +1425,7 @@ static hipError_t launch_mode(const KernelArgs& a, int mode, long n_items, long 
 
 template <int NB, int MODE>
 static hipError_t launch_solve_nb(const float* A, const float* b, float* x, long batch, int f, int cg_iters,
-                                  hipStream_t stream) {
+                                  hipStream_t stream, int a_half = 0) {
   const size_t floats = NB == 0 ? solve_lds_floats(f, kModeLUExact)
                                 : (MODE == kModeLU ? lu_lds_floats(NB, f) : solve_lds_floats(f, MODE));
   const size_t lds = floats * sizeof(float);
@@ -1420,7 +1436,7 @@ static hipError_t launch_solve_nb(const float* A, const float* b, float* x, long
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL((solve_lds_kernel<NB, MODE>), dim3((unsigned)batch), dim3(kThreads), lds, stream, A, b, x, f,
-                     cg_iters);
+                     cg_iters, a_half);
   return hipGetLastError();
 }
 
@@ -1476,8 +1492,9 @@ hipError_t slice_solve(const float* A, const float* b, float* x, long batch, int
   template <>                                                                                                    \
   hipError_t slice_solve<N>(const float* A, const float* b, float* x, long batch, int f, int mode, int cg_iters, \
                             hipStream_t stream) {                                                                \
-    if (mode == kModeCG) {                                                                                       \
-      if constexpr (N <= kMaxFusedNB) return launch_solve_nb<N, kModeCG>(A, b, x, batch, f, cg_iters, stream);   \
+    if (mode == kModeCG || mode == kModeCGHalf) {                                                                \
+      if constexpr (N <= kMaxFusedNB)                                                                            \
+        return launch_solve_nb<N, kModeCG>(A, b, x, batch, f, cg_iters, stream, mode == kModeCGHalf);            \
       return hipErrorInvalidValue;                                                                               \
     }                                                                                                            \
     return launch_solve_nb<N, kModeLU>(A, b, x, batch, f, cg_iters, stream);                                     \
@@ -1619,10 +1636,11 @@ hipError_t launch_solve_batched(const float* A, const float* b, float* x, long b
                                 hipStream_t stream) {
   if (batch <= 0) return hipSuccess;
   if (mode == kModeLUExact) return launch_solve_nb<0, kModeLU>(A, b, x, batch, f, 0, stream);
-  if (f > 128 && mode == kModeCG) {  // system too large for the LDS: A streamed from global memory
+  if (f > 128 && (mode == kModeCG || mode == kModeCGHalf)) {  // system too large for the LDS: A streamed from global memory
     const int threads = ((f + 63) / 64) * 64;
     const size_t lds = (threads + 16) * sizeof(float);
-    hipLaunchKernelGGL(cg_global_kernel, dim3((unsigned)batch), dim3(threads), lds, stream, A, x, b, f, cg_iters);
+    hipLaunchKernelGGL(cg_global_kernel, dim3((unsigned)batch), dim3(threads), lds, stream, A, x, b, f, cg_iters,
+                       (int)(mode == kModeCGHalf));
     return hipGetLastError();
   }
   // LDS-resident CG (f <= 128) or register-resident LU (f <= 200)

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "als_internal.h"
+#include "cg.h"
 #include "cumf_als_capi.h"
 
 using namespace cumf;
@@ -263,6 +264,28 @@ extern "C" int cumf_get_hermitian(const cumf_plan_t* p, const int* colidx, const
   return 0;
 }
 
+extern "C" int cumf_get_hermitian_fp16(const cumf_plan_t* p, const int* colidx, const float* val, const float* gather,
+                                       void* tt_half, float* rhs, int f, float lambda, void* stream) {
+  if (!p || f != p->f) {
+    fprintf(stderr, "cumf_get_hermitian_fp16: plan/f mismatch\n");
+    return (int)hipErrorInvalidValue;
+  }
+  KernelArgs a = base_args(p, colidx, val, gather, f, lambda);
+  a.tt = static_cast<float*>(tt_half);
+  a.tt_half = 1;
+  a.rhs = rhs;
+  CUMF_HIP_CHECK(launch_half_iteration(a, kModeMaterialize, p->n_items, p->n_mrows, static_cast<hipStream_t>(stream)));
+  return 0;
+}
+
+extern "C" int cumf_cg_solve_batched_fp16(const void* A_half, float* x, const float* b, long batch, int f,
+                                          int cg_iters, void* stream) {
+  if (f <= 0 || f > 256) return (int)hipErrorInvalidValue;
+  CUMF_HIP_CHECK(launch_solve_batched(static_cast<const float*>(A_half), b, x, batch, f, kModeCGHalf, cg_iters,
+                                      static_cast<hipStream_t>(stream)));
+  return 0;
+}
+
 extern "C" int cumf_cg_solve_batched(const float* A, float* x, const float* b, long batch, int f, int cg_iters,
                                      void* stream) {
   if (f <= 0 || f > 256) return (int)hipErrorInvalidValue;
@@ -342,6 +365,16 @@ extern "C" void cumf_rand_init(float* a, long count, float scale, long seed) {
 
 extern "C" int cumf_als_version(void) { return 100; }
 extern "C" const char* cumf_als_arch(void) { return "gfx950"; }
+
+// cg.h:32, cg.cu:641-644: A holds halves (the reference casts the float* it is handed: `(half*)A`)
+void updateXWithCGHost_tt_fp16(float* A, float* x, float* b, const int batchSize, const int f, const float cgIter) {
+  int rc = cumf_cg_solve_batched_fp16(A, x, b, batchSize, f, (int)ceilf(cgIter), nullptr);
+  hipError_t e = hipDeviceSynchronize();
+  if (rc != 0 || e != hipSuccess) {
+    fprintf(stderr, "updateXWithCGHost_tt_fp16 failed: %s\n", hipGetErrorString(rc ? (hipError_t)rc : e));
+    exit(EXIT_FAILURE);
+  }
+}
 
 // C++-linkage drop-in of the reference's inner solver API (cg.h:30, cg.cu:682-686):
 // device pointers, synchronous, aborts on error like cudaCheckError (als.h:667-674).

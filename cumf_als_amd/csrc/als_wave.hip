@@ -325,8 +325,8 @@ __device__ __forceinline__ void wave_tiles_to_partial(const f32x4 (&acc)[NB * (N
 }
 
 // row-major f x f Gram, both triangles, lambda * n on the diagonal (als.cu:545-566) + RHS
-template <int NB>
-__device__ __forceinline__ void wave_tiles_to_global(const f32x4 (&acc)[NB * (NB + 1) / 2], float* __restrict__ tt,
+template <int NB, typename T>
+__device__ __forceinline__ void wave_tiles_to_global(const f32x4 (&acc)[NB * (NB + 1) / 2], T* __restrict__ tt,
                                                      float* __restrict__ rhs, int f, float reg, int lane) {
   const int c = lane & 15, kk = lane >> 4;
   static_for<NB*(NB + 1) / 2>([&](auto tc) {
@@ -338,8 +338,8 @@ __device__ __forceinline__ void wave_tiles_to_global(const f32x4 (&acc)[NB * (NB
       float v = acc[t][r];
       if (i < f && j < f) {
         if (i == j) v += reg;
-        tt[(size_t)i * f + j] = v;
-        if (I != J) tt[(size_t)j * f + i] = v;
+        tt[(size_t)i * f + j] = (T)v;  // T = _Float16: fp16 Gram storage (als.cu:335-441), round to nearest even
+        if (I != J) tt[(size_t)j * f + i] = (T)v;
       } else if (i < f && j == f && rhs != nullptr) {
         rhs[i] = v;
       }
@@ -659,9 +659,12 @@ __global__ __launch_bounds__(64, CUMF_WAVE_MIN_WAVES) void als_wave_kernel(const
     return;
   }
   if constexpr (MODE == kModeMaterialize) {
-    float* tt = a.tt + (size_t)(row - a.row_begin) * f * f;
+    const size_t off = (size_t)(row - a.row_begin) * f * f;
     float* rhs = a.rhs ? a.rhs + (size_t)(row - a.row_begin) * f : nullptr;
-    wave_tiles_to_global<NB>(acc, tt, rhs, f, reg, lane);
+    if (a.tt_half)
+      wave_tiles_to_global<NB>(acc, reinterpret_cast<_Float16*>(a.tt) + off, rhs, f, reg, lane);
+    else
+      wave_tiles_to_global<NB>(acc, a.tt + off, rhs, f, reg, lane);
   } else {
     lu_wave<NB, FC>(acc, smem, f, reg, a.update + (size_t)row * f, lane);
   }

@@ -19,13 +19,14 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 # every extern "C" symbol declared in include/cumf_als_capi.h
 C_SYMBOLS = [
     "cumf_doALS", "cumf_doALS_ex", "cumf_plan_create", "cumf_plan_destroy", "cumf_plan_info",
-    "cumf_als_update_fused", "cumf_get_hermitian", "cumf_cg_solve_batched", "cumf_lu_solve_batched",
+    "cumf_als_update_fused", "cumf_get_hermitian", "cumf_get_hermitian_fp16", "cumf_cg_solve_batched_fp16", "cumf_set_tt_fp16", "cumf_get_tt_fp16", "cumf_cg_solve_batched", "cumf_lu_solve_batched",
     "cumf_pack_upper", "cumf_unpack_upper", "cumf_sse", "cumf_set_gram_mode", "cumf_get_gram_mode", "cumf_check_gather_table", "cumf_set_kernel_timing", "cumf_last_kernel_ms", "cumf_rand_init", "cumf_als_version", "cumf_als_arch",
 ]
 # C++-linkage drop-in symbols (include/als.h, include/cg.h) under the reference's mangled names
 CXX_SYMBOLS = [
     "_Z5doALSPKiS0_PKfS0_S0_S2_S0_PfS3_S0_S0_S2_iiillfiiii",
     "_Z17updateXWithCGHostPfS_S_iif",
+    "_Z25updateXWithCGHost_tt_fp16PfS_S_iif",
 ]
 
 _lib = None
@@ -65,6 +66,13 @@ def load():
     lib.cumf_als_update_fused.argtypes = [vp, ip, fp, fp, fp, C.c_int, C.c_float, C.c_int, C.c_int, vp]
     lib.cumf_get_hermitian.restype = C.c_int
     lib.cumf_get_hermitian.argtypes = [vp, ip, fp, fp, fp, fp, C.c_int, C.c_float, vp]
+    lib.cumf_get_hermitian_fp16.restype = C.c_int
+    lib.cumf_get_hermitian_fp16.argtypes = [vp, ip, fp, fp, vp, fp, C.c_int, C.c_float, vp]
+    lib.cumf_cg_solve_batched_fp16.restype = C.c_int
+    lib.cumf_cg_solve_batched_fp16.argtypes = [vp, fp, fp, C.c_long, C.c_int, C.c_int, vp]
+    lib.cumf_set_tt_fp16.restype = C.c_int
+    lib.cumf_set_tt_fp16.argtypes = [C.c_int]
+    lib.cumf_get_tt_fp16.restype = C.c_int
     lib.cumf_cg_solve_batched.restype = C.c_int
     lib.cumf_cg_solve_batched.argtypes = [fp, fp, fp, C.c_long, C.c_int, C.c_int, vp]
     lib.cumf_lu_solve_batched.restype = C.c_int

@@ -96,6 +96,25 @@ int cumf_als_update_fused(const cumf_plan_t* plan, const int* colidx, const floa
 int cumf_get_hermitian(const cumf_plan_t* plan, const int* colidx, const float* val,
                        const float* gather, float* tt, float* rhs, int f, float lambda, void* stream);
 
+/*
+ * fp16 storage of the Gram batch for the solver (the reference's compile-time switch CUMF_TT_FP16 /
+ * CUMF_XX_FP16: get_hermitian100_tt_fp16, als.cu:335-441; updateXWithCGKernel3, cg.cu:235-429;
+ * host updateXWithCGHost_tt_fp16, cg.h:32).  The Gram is accumulated in fp32 exactly as
+ * cumf_get_hermitian does and rounded to nearest-even fp16 on the store (__float2half_rn); the CG reads
+ * halves and computes in fp32.  Halves the Gram bytes of the unfused path; opt-in because it changes
+ * the numerics (the reference's author notes convergence problems with it).  tt_half / A_half:
+ * DEVICE buffers of (rows x f x f) 2-byte elements.
+ */
+int cumf_get_hermitian_fp16(const cumf_plan_t* plan, const int* colidx, const float* val, const float* gather,
+                            void* tt_half, float* rhs, int f, float lambda, void* stream);
+int cumf_cg_solve_batched_fp16(const void* A_half, float* x, const float* b, long batch, int f, int cg_iters,
+                               void* stream);
+/* doALS-level switch (process-wide; environment CUMF_ALS_TT_FP16=1): with the CG solver, doALS runs
+ * cumf_get_hermitian_fp16 + cumf_cg_solve_batched_fp16 per batch and prints "\tCG solver with fp16."
+ * (als.cu:826,936). */
+int cumf_set_tt_fp16(int enable);
+int cumf_get_tt_fp16(void);
+
 /* Batched CG on materialised systems; C alias of updateXWithCGHost (cg.h:30,
  * cg.cu:682-686): A batch x f x f, x batch x f (warm start in, solution out),
  * b batch x f, all DEVICE pointers.  Asynchronous on `stream`. */
