@@ -66,6 +66,9 @@ struct KernelArgs {
   float* tt;       // f x f Gram per row; holds _Float16 when tt_half (CUMF_TT_FP16 of als.cu:335-441)
   float* rhs;
   int tt_half;
+  // dense_slots: item i (wave kernel) / row i (reduce kernel) of this launch uses slot i of `part` and
+  // every item is dumped, none solved in place (batched "Gram -> tiles -> solver kernel" path)
+  int dense_slots;
   long long row_begin;
   int f;
   float lambda;
@@ -73,7 +76,21 @@ struct KernelArgs {
   int dbg;  // ablation switches for profiling (CUMF_ALS_DBG); 0 in production
 };
 
-hipError_t launch_half_iteration(const KernelArgs& a, int mode, long n_items, long n_mrows, hipStream_t stream);
+// Work lists of a plan as the launchers see them (device arrays of als_plan.cpp).
+struct PlanLists {
+  // all items, longest first (fused kernels)
+  long n_items, n_mrows;
+  // chunk items only (slot >= 0) and whole-row items only (slot < 0), each longest first
+  long n_citems, n_witems;
+  const int *c_row, *c_len, *c_slot, *c_rowlen;
+  const long long* c_begin;
+  const int *w_row, *w_len, *w_rowlen;
+  const long long* w_begin;
+  float* part2;      // dense-slot tile buffer of the batched path (lazily allocated), part2_rows slots
+  long part2_rows;
+};
+hipError_t launch_half_iteration(const KernelArgs& a, int mode, long n_items, long n_mrows, hipStream_t stream,
+                                 const PlanLists* lists = nullptr);
 hipError_t launch_solve_batched(const float* A, const float* b, float* x, long batch, int f, int mode, int cg_iters,
                                 hipStream_t stream);
 // Gram arithmetic of the fused / materialising passes.
@@ -85,6 +102,8 @@ enum { kGramAuto = 0, kGramExact = 1 };
 void set_gram_mode(int mode);
 int gram_mode();
 bool wave_path_available(int f, int mode);
+// CG on the wave kernels' Gram: Gram -> tiles (dense slots, batches of <= 2 GiB) -> solver kernel
+bool wave_batched_path(int f, int mode);
 // unpack = 0: full (batch x f x f) -> packed (batch x f(f+1)/2); unpack = 1: `full` is the packed input,
 // `packed` receives the mirrored full matrices
 hipError_t launch_pack_upper(const float* full, float* packed, long batch, int f, int unpack, hipStream_t stream);

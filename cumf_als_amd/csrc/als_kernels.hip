@@ -1129,8 +1129,8 @@ __global__ __launch_bounds__(kThreads) void als_reduce_kernel(const KernelArgs a
   const int tid = threadIdx.x, lane = tid & 63;
   const int mr = blockIdx.x;
   const int row = a.mrow_row[mr];
-  const int slot0 = a.mrow_slot0[mr];
-  const int nslots = a.mrow_nslots[mr];
+  const int slot0 = a.dense_slots ? mr : a.mrow_slot0[mr];
+  const int nslots = a.dense_slots ? 1 : a.mrow_nslots[mr];
   const int rowlen = a.mrow_rowlen[mr];
   switch (tid >> 6) {
     case 0: reduce_body<NB, MODE, 0>(smem, a, row, slot0, nslots, rowlen, lane); break;
@@ -1446,6 +1446,19 @@ static hipError_t launch_reduce_only(const KernelArgs& a, int mode, long n_mrows
   if (n_mrows <= 0) return hipSuccess;
   if (mode == kModeMaterialize) {
     hipLaunchKernelGGL((als_reduce_kernel<NB, kModeMaterialize>), dim3((unsigned)n_mrows), dim3(kThreads), 0, stream, a);
+  } else if (mode == kModeCG) {
+    if constexpr (NB <= kMaxFusedNB) {
+      if (a.f > kVecLd) return hipErrorInvalidValue;
+      const size_t lds = solve_lds_floats(a.f, kModeCG) * sizeof(float);
+      if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(als_reduce_kernel<NB, kModeCG>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+      }
+      hipLaunchKernelGGL((als_reduce_kernel<NB, kModeCG>), dim3((unsigned)n_mrows), dim3(kThreads), lds, stream, a);
+    } else {
+      return hipErrorInvalidValue;
+    }
   } else {
     const size_t lds = lu_lds_floats(NB, a.f) * sizeof(float);
     hipLaunchKernelGGL((als_reduce_kernel<NB, kModeLU>), dim3((unsigned)n_mrows), dim3(kThreads), lds, stream, a);
@@ -1454,6 +1467,63 @@ static hipError_t launch_reduce_only(const KernelArgs& a, int mode, long n_mrows
 }
 template <int NB>
 hipError_t slice_reduce_only(const KernelArgs& a, int mode, long n_mrows, hipStream_t stream);
+
+// wave-per-item kernels (als_wave.hip), one translation unit per NB
+template <int NB>
+hipError_t wave_item_launch(const KernelArgs& a, int mode, long n_items, hipStream_t stream);
+#define CUMF_DECLARE_WAVE(N) \
+  template <>                \
+  hipError_t wave_item_launch<N>(const KernelArgs& a, int mode, long n_items, hipStream_t stream);
+CUMF_DECLARE_WAVE(2) CUMF_DECLARE_WAVE(3) CUMF_DECLARE_WAVE(4) CUMF_DECLARE_WAVE(5)
+CUMF_DECLARE_WAVE(6) CUMF_DECLARE_WAVE(7)
+
+// CG on the wave kernels' Gram (the reference's default solver, als.cu:28): the Gram of every row is
+// dumped as accumulator tiles and a solver kernel (als_reduce_kernel: sums the slots of a chunked row,
+// then the 4-wave LDS-resident CG of cg.cu:36-231) picks them up -- the reference's own data flow
+// ("Gram batch in device memory, separate solver", als.cu:782-831), with tiles instead of full f x f
+// matrices and in batches of <= 2 GiB that stay L2 / MALL-warm.
+template <int NB>
+static hipError_t launch_batched_nb(const KernelArgs& a0, int mode, const PlanLists& L, hipStream_t stream) {
+  if constexpr (NB < 2 || NB > kMaxWaveNB) {
+    return hipErrorInvalidValue;
+  } else {
+  hipError_t e = hipSuccess;
+  // 1. chunked rows: their items write the plan's slots, the reduce kernel sums and solves
+  if (L.n_citems > 0) {
+    KernelArgs a = a0;
+    a.item_row = L.c_row;
+    a.item_begin = L.c_begin;
+    a.item_len = L.c_len;
+    a.item_slot = L.c_slot;
+    a.item_rowlen = L.c_rowlen;
+    e = wave_item_launch<NB>(a, kModeLU, L.n_citems, stream);  // every item has a slot: nothing is solved in place
+    if (e != hipSuccess) return e;
+    e = launch_reduce_only<NB>(a0, mode, L.n_mrows, stream);
+    if (e != hipSuccess) return e;
+  }
+  // 2. whole rows, in batches of part2_rows dense slots
+  for (long w0 = 0; w0 < L.n_witems; w0 += L.part2_rows) {
+    const long cnt = L.n_witems - w0 < L.part2_rows ? L.n_witems - w0 : L.part2_rows;
+    KernelArgs a = a0;
+    a.item_row = L.w_row + w0;
+    a.item_begin = L.w_begin + w0;
+    a.item_len = L.w_len + w0;
+    a.item_rowlen = L.w_rowlen + w0;
+    a.item_slot = nullptr;
+    a.dense_slots = 1;
+    a.part = L.part2;
+    a.mrow_row = L.w_row + w0;
+    a.mrow_rowlen = L.w_rowlen + w0;
+    e = wave_item_launch<NB>(a, kModeLU, cnt, stream);
+    if (e != hipSuccess) return e;
+    e = launch_reduce_only<NB>(a, mode, cnt, stream);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+  }
+}
+template <int NB>
+hipError_t slice_batched(const KernelArgs& a, int mode, const PlanLists& L, hipStream_t stream);
 
 // Per-NB entry points (one translation unit each, see CUMF_NB_SLICE above).
 template <int NB>
@@ -1469,7 +1539,9 @@ hipError_t slice_solve(const float* A, const float* b, float* x, long batch, int
   hipError_t slice_solve<N>(const float* A, const float* b, float* x, long batch, int f, int mode, int cg_iters, \
                             hipStream_t stream);                                                                 \
   template <>                                                                                                    \
-  hipError_t slice_reduce_only<N>(const KernelArgs& a, int mode, long n_mrows, hipStream_t stream);
+  hipError_t slice_reduce_only<N>(const KernelArgs& a, int mode, long n_mrows, hipStream_t stream);              \
+  template <>                                                                                                    \
+  hipError_t slice_batched<N>(const KernelArgs& a, int mode, const PlanLists& L, hipStream_t stream);
 #define CUMF_STUB_SLICE(N)                                                                                       \
   template <>                                                                                                    \
   hipError_t slice_half_iteration<N>(const KernelArgs&, int, long, long, hipStream_t) {                          \
@@ -1481,6 +1553,10 @@ hipError_t slice_solve(const float* A, const float* b, float* x, long batch, int
   }                                                                                                              \
   template <>                                                                                                    \
   hipError_t slice_reduce_only<N>(const KernelArgs&, int, long, hipStream_t) {                                   \
+    return hipErrorInvalidValue;                                                                                 \
+  }                                                                                                              \
+  template <>                                                                                                    \
+  hipError_t slice_batched<N>(const KernelArgs&, int, const PlanLists&, hipStream_t) {                           \
     return hipErrorInvalidValue;                                                                                 \
   }
 #define CUMF_DEFINE_SLICE(N)                                                                                     \
@@ -1502,6 +1578,10 @@ hipError_t slice_solve(const float* A, const float* b, float* x, long batch, int
   template <>                                                                                                    \
   hipError_t slice_reduce_only<N>(const KernelArgs& a, int mode, long n_mrows, hipStream_t stream) {             \
     return launch_reduce_only<N>(a, mode, n_mrows, stream);                                                      \
+  }                                                                                                              \
+  template <>                                                                                                    \
+  hipError_t slice_batched<N>(const KernelArgs& a, int mode, const PlanLists& L, hipStream_t stream) {           \
+    return launch_batched_nb<N>(a, mode, L, stream);                                                             \
   }
 
 CUMF_DECLARE_SLICE(1) CUMF_DECLARE_SLICE(2) CUMF_DECLARE_SLICE(3) CUMF_DECLARE_SLICE(4) CUMF_DECLARE_SLICE(5)
@@ -1576,15 +1656,6 @@ CUMF_STUB_SLICE(13)
 #if CUMF_SLICE_COMMON
 #define CUMF_NB_CASE(N, call) case N: return call;
 
-// wave-per-item kernels (als_wave.hip), one translation unit per NB
-template <int NB>
-hipError_t wave_item_launch(const KernelArgs& a, int mode, long n_items, hipStream_t stream);
-#define CUMF_DECLARE_WAVE(N) \
-  template <>                \
-  hipError_t wave_item_launch<N>(const KernelArgs& a, int mode, long n_items, hipStream_t stream);
-CUMF_DECLARE_WAVE(2) CUMF_DECLARE_WAVE(3) CUMF_DECLARE_WAVE(4) CUMF_DECLARE_WAVE(5)
-CUMF_DECLARE_WAVE(6) CUMF_DECLARE_WAVE(7)
-
 static int g_gram_mode = -1;
 void set_gram_mode(int mode) { g_gram_mode = mode == kGramExact ? kGramExact : kGramAuto; }
 int gram_mode() {
@@ -1602,7 +1673,31 @@ bool wave_path_available(int f, int mode) {
          (mode == kModeLU || mode == kModeMaterialize);
 }
 
-hipError_t launch_half_iteration(const KernelArgs& a, int mode, long n_items, long n_mrows, hipStream_t stream) {
+bool wave_batched_path(int f, int mode) {
+  // CG warm-starts from and overwrites `update`; its fused 4-wave solver (cg_solve_lds) needs f <= 128
+  return gram_mode() != kGramExact && mode == kModeCG && nb_for_f(f) >= 2 && nb_for_f(f) <= kMaxWaveNB &&
+         f <= kVecLd && !getenv("CUMF_ALS_NO_BATCHED_CG");
+}
+
+hipError_t launch_half_iteration(const KernelArgs& a, int mode, long n_items, long n_mrows, hipStream_t stream,
+                                 const PlanLists* lists) {
+  if (lists != nullptr && wave_batched_path(a.f, mode)) {
+    if (g_timing) (void)hipEventRecord(g_ev[0], stream);
+    g_timed_item = true;
+    g_timed_reduce = false;
+    hipError_t e = hipErrorInvalidValue;
+    switch (nb_for_f(a.f)) {
+#define CUMF_BATCHED(N) case N: e = slice_batched<N>(a, mode, *lists, stream); break;
+      CUMF_BATCHED(2) CUMF_BATCHED(3) CUMF_BATCHED(4) CUMF_BATCHED(5) CUMF_BATCHED(6) CUMF_BATCHED(7)
+#undef CUMF_BATCHED
+      default: break;
+    }
+    if (g_timing) {
+      (void)hipEventRecord(g_ev[1], stream);
+      (void)hipEventRecord(g_ev[2], stream);
+    }
+    return e;
+  }
   if (wave_path_available(a.f, mode)) {
     if (g_timing) (void)hipEventRecord(g_ev[0], stream);
     g_timed_item = n_items > 0;

@@ -26,6 +26,7 @@ using namespace cumf;
 struct cumf_plan {
   long rows = 0, row_begin = 0, row_end = 0;
   int f = 0, nb = 0, chunk = 0;
+  long long plan_nnz = 0;  // ratings of the planned rows
   long n_items = 0, n_slots = 0, n_mrows = 0;
   int* d_item_row = nullptr;
   long long* d_item_begin = nullptr;
@@ -37,6 +38,15 @@ struct cumf_plan {
   int* d_mrow_nslots = nullptr;
   int* d_mrow_rowlen = nullptr;
   float* d_part = nullptr;
+  // chunk-only / whole-row-only item lists and the dense-slot tile buffer of the batched
+  // "Gram -> tiles -> solver kernel" path (CG on the wave kernels' Gram)
+  long n_citems = 0, n_witems = 0;
+  int *d_c_row = nullptr, *d_c_len = nullptr, *d_c_slot = nullptr, *d_c_rowlen = nullptr;
+  long long* d_c_begin = nullptr;
+  int *d_w_row = nullptr, *d_w_len = nullptr, *d_w_rowlen = nullptr;
+  long long* d_w_begin = nullptr;
+  float* d_part2 = nullptr;
+  long part2_rows = 0;
 };
 
 namespace {
@@ -147,6 +157,23 @@ extern "C" int cumf_plan_create(cumf_plan_t** out, const void* rowptr_host, int 
   permute(item_slot);
   permute(item_rowlen);
 
+  std::vector<int> c_row, c_len, c_slot, c_rowlen, w_row, w_len, w_rowlen;
+  std::vector<long long> c_begin, w_begin;
+  for (size_t i = 0; i < item_row.size(); ++i) {  // the sorted order carries over to both sub-lists
+    if (item_slot[i] >= 0) {
+      c_row.push_back(item_row[i]);
+      c_begin.push_back(item_begin[i]);
+      c_len.push_back(item_len[i]);
+      c_slot.push_back(item_slot[i]);
+      c_rowlen.push_back(item_rowlen[i]);
+    } else {
+      w_row.push_back(item_row[i]);
+      w_begin.push_back(item_begin[i]);
+      w_len.push_back(item_len[i]);
+      w_rowlen.push_back(item_rowlen[i]);
+    }
+  }
+
   cumf_plan* p = new cumf_plan();
   p->rows = rows;
   p->row_begin = row_begin;
@@ -154,6 +181,7 @@ extern "C" int cumf_plan_create(cumf_plan_t** out, const void* rowptr_host, int 
   p->f = f;
   p->nb = nb_for_f(f);
   p->chunk = chunk;
+  p->plan_nnz = rp(row_end) - rp(row_begin);
   p->n_items = (long)item_row.size();
   p->n_slots = n_slots;
   p->n_mrows = (long)mrow_row.size();
@@ -177,6 +205,17 @@ extern "C" int cumf_plan_create(cumf_plan_t** out, const void* rowptr_host, int 
   PLAN_CHECK(upload(&p->d_mrow_slot0, mrow_slot0));
   PLAN_CHECK(upload(&p->d_mrow_nslots, mrow_nslots));
   PLAN_CHECK(upload(&p->d_mrow_rowlen, mrow_rowlen));
+  p->n_citems = (long)c_row.size();
+  p->n_witems = (long)w_row.size();
+  PLAN_CHECK(upload(&p->d_c_row, c_row));
+  PLAN_CHECK(upload(&p->d_c_begin, c_begin));
+  PLAN_CHECK(upload(&p->d_c_len, c_len));
+  PLAN_CHECK(upload(&p->d_c_slot, c_slot));
+  PLAN_CHECK(upload(&p->d_c_rowlen, c_rowlen));
+  PLAN_CHECK(upload(&p->d_w_row, w_row));
+  PLAN_CHECK(upload(&p->d_w_begin, w_begin));
+  PLAN_CHECK(upload(&p->d_w_len, w_len));
+  PLAN_CHECK(upload(&p->d_w_rowlen, w_rowlen));
   if (n_slots > 0) {
     const size_t tiles = (size_t)p->nb * (p->nb + 1) / 2;
     PLAN_CHECK(hipMalloc(reinterpret_cast<void**>(&p->d_part), (size_t)n_slots * tiles * 256 * sizeof(float)));
@@ -189,7 +228,9 @@ extern "C" int cumf_plan_create(cumf_plan_t** out, const void* rowptr_host, int 
 extern "C" int cumf_plan_destroy(cumf_plan_t* p) {
   if (!p) return 0;
   void* ptrs[] = {p->d_item_row,  p->d_item_begin,  p->d_item_len,    p->d_item_slot,   p->d_item_rowlen,
-                  p->d_mrow_row,  p->d_mrow_slot0,  p->d_mrow_nslots, p->d_mrow_rowlen, p->d_part};
+                  p->d_mrow_row,  p->d_mrow_slot0,  p->d_mrow_nslots, p->d_mrow_rowlen, p->d_part,
+                  p->d_c_row,     p->d_c_begin,     p->d_c_len,       p->d_c_slot,      p->d_c_rowlen,
+                  p->d_w_row,     p->d_w_begin,     p->d_w_len,       p->d_w_rowlen,    p->d_part2};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   delete p;
@@ -206,6 +247,23 @@ extern "C" int cumf_plan_info(const cumf_plan_t* p, long info[4]) {
 }
 
 namespace {
+
+// Dense-slot tile buffer of the batched path: at most 2 GiB (74 898 systems at f = 100), allocated on
+// first use and kept with the plan.
+int plan_lists(const cumf_plan_t* cp, PlanLists* out) {
+  cumf_plan* p = const_cast<cumf_plan*>(cp);
+  const size_t tile_bytes = (size_t)p->nb * (p->nb + 1) / 2 * 256 * sizeof(float);
+  if (!p->d_part2 && p->n_witems > 0) {
+    long rows = (long)std::min<size_t>((size_t)p->n_witems, ((size_t)2 << 30) / tile_bytes);
+    if (rows < 1) rows = 1;
+    CUMF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p->d_part2), (size_t)rows * tile_bytes));
+    p->part2_rows = rows;
+  }
+  *out = PlanLists{p->n_items,  p->n_mrows, p->n_citems, p->n_witems, p->d_c_row,    p->d_c_len,  p->d_c_slot,
+                   p->d_c_rowlen, p->d_c_begin, p->d_w_row,  p->d_w_len,  p->d_w_rowlen, p->d_w_begin, p->d_part2,
+                   p->part2_rows};
+  return 0;
+}
 
 KernelArgs base_args(const cumf_plan_t* p, const int* colidx, const float* val, const float* gather, int f,
                      float lambda) {
@@ -249,7 +307,19 @@ extern "C" int cumf_als_update_fused(const cumf_plan_t* p, const int* colidx, co
   a.update = update;
   a.cg_iters = cg_iters;
   const int mode = (solver == CUMF_SOLVER_LU) ? kModeLU : kModeCG;
-  CUMF_HIP_CHECK(launch_half_iteration(a, mode, p->n_items, p->n_mrows, static_cast<hipStream_t>(stream)));
+  PlanLists lists{};
+  // The tile round trip of the batched path is 2 x 28 KB per row at f = 100: worth it when the Gram of a
+  // row is long (Netflix: 206 .. 5 575 ratings per row: CG 29.4 -> 22.2 ms per iteration), not for
+  // hugewiki's 62-rating rows (measured 165 -> 186 ms), which stay on the fused workgroup kernel.
+  const long long plan_nnz_rows = p->row_end - p->row_begin;
+  const bool long_rows = plan_nnz_rows > 0 && p->plan_nnz / plan_nnz_rows >= 128;
+  const bool batched = wave_batched_path(f, mode) && (long_rows || getenv("CUMF_ALS_FORCE_BATCHED"));
+  if (batched) {
+    const int rc = plan_lists(p, &lists);
+    if (rc) return rc;
+  }
+  CUMF_HIP_CHECK(launch_half_iteration(a, mode, p->n_items, p->n_mrows, static_cast<hipStream_t>(stream),
+                                       batched ? &lists : nullptr));
   return 0;
 }
 

@@ -605,7 +605,7 @@ __global__ __launch_bounds__(64, CUMF_WAVE_MIN_WAVES) void als_wave_kernel(const
   const int row = a.item_row[item];
   const long long begin = a.item_begin[item];
   const int len = a.item_len[item];
-  const int slot = a.item_slot[item];
+  const int slot = a.dense_slots ? item : a.item_slot[item];
   const int rowlen = a.item_rowlen[item];
   const int f = FC ? FC : a.f;
   // Two waves share a SIMD.  Left alone they fall into lockstep (both in their MFMA phase, then both
