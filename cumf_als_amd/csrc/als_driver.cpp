@@ -99,7 +99,7 @@ extern "C" float cumf_doALS_ex(const int* csrRowIndexHostPtr, const int* csrColI
   if (!quiet) printf("*******parameters: m: %d, n:  %d, f: %d, nnz: %ld \n", m, n, f, nnz);
   if (X_BATCH < 1) X_BATCH = 1;
   if (THETA_BATCH < 1) THETA_BATCH = 1;
-  if (!cumf::fused_supported(f, solver == CUMF_SOLVER_LU ? cumf::kModeLU : cumf::kModeCG)) fused = 0;  // CG: f <= 128
+  if (!cumf_fused_available(f, solver)) fused = 0;
   // fp16 storage of the Gram batch (als.cu:779-783, 893-895): the reference's data flow by construction
   // (Gram batch in device memory + updateXWithCGHost_tt_fp16); CG only, like the reference
   const int tt_fp16 = cumf_get_tt_fp16() && solver == CUMF_SOLVER_CG;

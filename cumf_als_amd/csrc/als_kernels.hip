@@ -1440,10 +1440,33 @@ static hipError_t launch_solve_nb(const float* A, const float* b, float* x, long
   return hipGetLastError();
 }
 
+// wave-per-item kernels (als_wave.hip), one translation unit per NB
+template <int NB>
+hipError_t wave_item_launch(const KernelArgs& a, int mode, long n_items, hipStream_t stream);
+template <int NB>
+hipError_t wave_solve_launch(const KernelArgs& a, int mode, long n_rows, hipStream_t stream);
+#define CUMF_DECLARE_WAVE(N)                                                                       \
+  template <>                                                                                      \
+  hipError_t wave_item_launch<N>(const KernelArgs& a, int mode, long n_items, hipStream_t stream); \
+  template <>                                                                                      \
+  hipError_t wave_solve_launch<N>(const KernelArgs& a, int mode, long n_rows, hipStream_t stream);
+CUMF_DECLARE_WAVE(2) CUMF_DECLARE_WAVE(3) CUMF_DECLARE_WAVE(4) CUMF_DECLARE_WAVE(5)
+CUMF_DECLARE_WAVE(6) CUMF_DECLARE_WAVE(7) CUMF_DECLARE_WAVE(8) CUMF_DECLARE_WAVE(9) CUMF_DECLARE_WAVE(10)
+CUMF_DECLARE_WAVE(11) CUMF_DECLARE_WAVE(12) CUMF_DECLARE_WAVE(13)
+
 // reduce kernel of the chunked rows on its own (the items came from the wave-per-item kernel)
 template <int NB>
 static hipError_t launch_reduce_only(const KernelArgs& a, int mode, long n_mrows, hipStream_t stream) {
   if (n_mrows <= 0) return hipSuccess;
+  if constexpr (NB >= 2) {
+    if (gram_mode() != kGramExact && !getenv("CUMF_ALS_NO_WAVE_SOLVE")) {
+      // CG on the tiles at wave level: the chunked rows of the wave kernels (NB <= 7) and the systems too
+      // large for the LDS-resident 4-wave CG (f > 128; two waves share the tiles).  NB = 8, 9 (f = 112 ..
+      // 128) stay on the 4-wave solvers: measured 38.8 vs 56.3 ms (CG) and 49.0 vs 62.2 ms (LU) per Netflix
+      // iteration at f = 128 -- one wave holding 45 tiles spills and has nobody to overlap with.
+      if (mode == kModeCG && (NB <= kMaxWaveNB || a.f > kVecLd)) return wave_solve_launch<NB>(a, mode, n_mrows, stream);
+    }
+  }
   if (mode == kModeMaterialize) {
     hipLaunchKernelGGL((als_reduce_kernel<NB, kModeMaterialize>), dim3((unsigned)n_mrows), dim3(kThreads), 0, stream, a);
   } else if (mode == kModeCG) {
@@ -1461,6 +1484,11 @@ static hipError_t launch_reduce_only(const KernelArgs& a, int mode, long n_mrows
     }
   } else {
     const size_t lds = lu_lds_floats(NB, a.f) * sizeof(float);
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(als_reduce_kernel<NB, kModeLU>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL((als_reduce_kernel<NB, kModeLU>), dim3((unsigned)n_mrows), dim3(kThreads), lds, stream, a);
   }
   return hipGetLastError();
@@ -1468,23 +1496,15 @@ static hipError_t launch_reduce_only(const KernelArgs& a, int mode, long n_mrows
 template <int NB>
 hipError_t slice_reduce_only(const KernelArgs& a, int mode, long n_mrows, hipStream_t stream);
 
-// wave-per-item kernels (als_wave.hip), one translation unit per NB
-template <int NB>
-hipError_t wave_item_launch(const KernelArgs& a, int mode, long n_items, hipStream_t stream);
-#define CUMF_DECLARE_WAVE(N) \
-  template <>                \
-  hipError_t wave_item_launch<N>(const KernelArgs& a, int mode, long n_items, hipStream_t stream);
-CUMF_DECLARE_WAVE(2) CUMF_DECLARE_WAVE(3) CUMF_DECLARE_WAVE(4) CUMF_DECLARE_WAVE(5)
-CUMF_DECLARE_WAVE(6) CUMF_DECLARE_WAVE(7)
 
-// CG on the wave kernels' Gram (the reference's default solver, als.cu:28): the Gram of every row is
-// dumped as accumulator tiles and a solver kernel (als_reduce_kernel: sums the slots of a chunked row,
-// then the 4-wave LDS-resident CG of cg.cu:36-231) picks them up -- the reference's own data flow
-// ("Gram batch in device memory, separate solver", als.cu:782-831), with tiles instead of full f x f
-// matrices and in batches of <= 2 GiB that stay L2 / MALL-warm.
+// Large systems (f >= 112): the Gram of every row is dumped as accumulator tiles (two waves per item,
+// als_wave_multi_kernel) and a solver kernel (single-wave LU up to NB = 10, the 4-wave lu_solve_mfma
+// above that, wave-level CG on the tiles) picks them up -- the reference's own data flow ("Gram batch
+// in device memory, separate solver", als.cu:782-831), with tiles instead of full f x f matrices and
+// in batches of <= 2 GiB.
 template <int NB>
 static hipError_t launch_batched_nb(const KernelArgs& a0, int mode, const PlanLists& L, hipStream_t stream) {
-  if constexpr (NB < 2 || NB > kMaxWaveNB) {
+  if constexpr (NB < 2) {
     return hipErrorInvalidValue;
   } else {
   hipError_t e = hipSuccess;
@@ -1670,13 +1690,15 @@ bool wave_path_available(int f, int mode) {
   // workgroup kernels: measured 0.56 vs 3.4 ms per iteration at f = 10, while f = 20 .. 48 is 1.4-1.7x
   // faster on the wave kernels
   return gram_mode() != kGramExact && nb_for_f(f) >= 2 && nb_for_f(f) <= kMaxWaveNB &&
-         (mode == kModeLU || mode == kModeMaterialize);
+         (mode == kModeLU || mode == kModeMaterialize || mode == kModeCG);
 }
 
 bool wave_batched_path(int f, int mode) {
-  // CG warm-starts from and overwrites `update`; its fused 4-wave solver (cg_solve_lds) needs f <= 128
-  return gram_mode() != kGramExact && mode == kModeCG && nb_for_f(f) >= 2 && nb_for_f(f) <= kMaxWaveNB &&
-         f <= kVecLd && !getenv("CUMF_ALS_NO_BATCHED_CG");
+  if (gram_mode() == kGramExact || getenv("CUMF_ALS_NO_BATCHED")) return false;
+  const int nb = nb_for_f(f);
+  // f >= 112 (NB 8 .. 13): two waves per item form the Gram, a solver kernel picks the tiles up
+  // (f <= 111: everything runs inside the wave-per-item kernel, see wave_path_available)
+  return nb > kMaxWaveNB && nb <= nb_for_f(kMaxF) && (mode == kModeLU || mode == kModeMaterialize || mode == kModeCG);
 }
 
 hipError_t launch_half_iteration(const KernelArgs& a, int mode, long n_items, long n_mrows, hipStream_t stream,
@@ -1688,7 +1710,7 @@ hipError_t launch_half_iteration(const KernelArgs& a, int mode, long n_items, lo
     hipError_t e = hipErrorInvalidValue;
     switch (nb_for_f(a.f)) {
 #define CUMF_BATCHED(N) case N: e = slice_batched<N>(a, mode, *lists, stream); break;
-      CUMF_BATCHED(2) CUMF_BATCHED(3) CUMF_BATCHED(4) CUMF_BATCHED(5) CUMF_BATCHED(6) CUMF_BATCHED(7)
+      CUMF_BATCHED(8) CUMF_BATCHED(9) CUMF_BATCHED(10) CUMF_BATCHED(11) CUMF_BATCHED(12) CUMF_BATCHED(13)
 #undef CUMF_BATCHED
       default: break;
     }

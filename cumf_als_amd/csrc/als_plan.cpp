@@ -291,13 +291,21 @@ KernelArgs base_args(const cumf_plan_t* p, const int* colidx, const float* val, 
 
 }  // namespace
 
+// Can one fused call (RHS + Gram + solve) handle (f, solver)?  The workgroup kernels: CG f <= 128, LU
+// f <= 200; the wave kernels and the tile-batched path (gram mode auto): both solvers up to f = 207.
+extern "C" int cumf_fused_available(int f, int solver) {
+  const int mode = solver == CUMF_SOLVER_LU ? kModeLU : kModeCG;
+  if (f <= 0 || f > kMaxF || (f % 2) != 0) return 0;
+  return fused_supported(f, mode) || wave_path_available(f, mode) || wave_batched_path(f, mode);
+}
+
 extern "C" int cumf_als_update_fused(const cumf_plan_t* p, const int* colidx, const float* val, const float* gather,
                                      float* update, int f, float lambda, int solver, int cg_iters, void* stream) {
   if (!p || f != p->f) {
     fprintf(stderr, "cumf_als_update_fused: plan/f mismatch\n");
     return (int)hipErrorInvalidValue;
   }
-  if (!fused_supported(f, solver == CUMF_SOLVER_LU ? kModeLU : kModeCG)) {
+  if (!cumf_fused_available(f, solver)) {
     fprintf(stderr, "cumf_als_update_fused: f = %d with this solver needs the materialising path "
                     "(cumf_get_hermitian + cumf_*_solve_batched): the fused CG holds the full system "
                     "in LDS (f <= 128), the fused LU its packed upper triangle (f <= 200)\n", f);
@@ -313,7 +321,8 @@ extern "C" int cumf_als_update_fused(const cumf_plan_t* p, const int* colidx, co
   // hugewiki's 62-rating rows (measured 165 -> 186 ms), which stay on the fused workgroup kernel.
   const long long plan_nnz_rows = p->row_end - p->row_begin;
   const bool long_rows = plan_nnz_rows > 0 && p->plan_nnz / plan_nnz_rows >= 128;
-  const bool batched = wave_batched_path(f, mode) && (long_rows || getenv("CUMF_ALS_FORCE_BATCHED"));
+  (void)long_rows;
+  const bool batched = wave_batched_path(f, mode);
   if (batched) {
     const int rc = plan_lists(p, &lists);
     if (rc) return rc;
@@ -332,7 +341,14 @@ extern "C" int cumf_get_hermitian(const cumf_plan_t* p, const int* colidx, const
   KernelArgs a = base_args(p, colidx, val, gather, f, lambda);
   a.tt = tt;
   a.rhs = rhs;
-  CUMF_HIP_CHECK(launch_half_iteration(a, kModeMaterialize, p->n_items, p->n_mrows, static_cast<hipStream_t>(stream)));
+  PlanLists lists{};
+  const bool batched = wave_batched_path(f, kModeMaterialize);
+  if (batched) {
+    const int rc = plan_lists(p, &lists);
+    if (rc) return rc;
+  }
+  CUMF_HIP_CHECK(launch_half_iteration(a, kModeMaterialize, p->n_items, p->n_mrows, static_cast<hipStream_t>(stream),
+                                       batched ? &lists : nullptr));
   return 0;
 }
 
@@ -346,7 +362,14 @@ extern "C" int cumf_get_hermitian_fp16(const cumf_plan_t* p, const int* colidx, 
   a.tt = static_cast<float*>(tt_half);
   a.tt_half = 1;
   a.rhs = rhs;
-  CUMF_HIP_CHECK(launch_half_iteration(a, kModeMaterialize, p->n_items, p->n_mrows, static_cast<hipStream_t>(stream)));
+  PlanLists lists{};
+  const bool batched = wave_batched_path(f, kModeMaterialize);
+  if (batched) {
+    const int rc = plan_lists(p, &lists);
+    if (rc) return rc;
+  }
+  CUMF_HIP_CHECK(launch_half_iteration(a, kModeMaterialize, p->n_items, p->n_mrows, static_cast<hipStream_t>(stream),
+                                       batched ? &lists : nullptr));
   return 0;
 }
 
@@ -400,6 +423,7 @@ extern "C" int cumf_check_gather_table(long gather_rows, int f, int solver, int 
   const int mode = materialize ? kModeMaterialize : (solver == CUMF_SOLVER_LU ? kModeLU : kModeCG);
   if (gather_rows < 0 || f <= 0) return (int)hipErrorInvalidValue;
   if (wave_path_available(f, mode)) return 0;
+  if (nb_for_f(f) > kMaxWaveNB && wave_batched_path(f, mode)) return 0;  // two-waves-per-item Gram: 64-bit addresses too
   const unsigned long long bytes = (unsigned long long)gather_rows * (unsigned long long)f * 4ull;
   if (bytes >= (1ull << 32)) {
     fprintf(stderr,

@@ -49,6 +49,9 @@ typedef int i32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef __attribute__((address_space(3))) float* lds_float_ptr;  // LDS pointer kept in its own address space (M0 operand)
 
+#ifndef CUMF_WAVE_NB
+#error "compile with -DCUMF_WAVE_NB=<feature blocks>"
+#endif
 #ifndef CUMF_WAVE_VARIANT
 #define CUMF_WAVE_VARIANT 0  // experiment switches (tools/wave_variants.sh)
 #endif
@@ -589,6 +592,249 @@ __device__ __forceinline__ void lu_wave(f32x4 (&acc)[NB * (NB + 1) / 2], float* 
 }
 
 // ----------------------------------------------------------------------------------
+// Conjugate gradient on dumped tiles (cg.cu:36-231: warm start, r = b - A x, <= cg_iters iterations,
+// stop when ||r||^2 < 1e-4), NW waves per system, wave W holding the tiles t % NW == W in registers.
+// Vectors live in "column layout": one register per 16-feature block, lane (g, c) = element
+// 16 J + c, replicated over the four lane groups g; every wave keeps all vectors and performs the
+// vector updates and dot products redundantly (identical instruction sequences on identical data:
+// alpha / beta / the exit test are uniform without communication).  Mat-vec y = A v on a tile
+// T = T(I, J), I <= J, in the C/D layout (lane (g, c), register r = T[4 g + r][c]):
+//   (1) y_I[4 g + r] += sum_c T[r][c] v_J[c]        4 FMAs, then a 16-lane DPP reduction per (I, r)
+//   (2) y_J[c]       += sum_{g, r} T[r][c] v_I[4 g + r]   (I < J: the mirrored half)   4 FMAs with v_I in
+//       "row layout" (ds_bpermute from the column layout), then a 4-lane-group reduction per J
+// and (1)'s result is brought back to the column layout with 3 selects + 1 ds_bpermute per block.
+// NW > 1: the partial y of the waves go through LDS, one workgroup barrier pair per mat-vec.
+// Dot products: per-lane FMAs over the blocks + the 16-lane DPP reduction (fixed order), in place of
+// the reference's order-dependent shared-memory atomics (device_utilities.h:36-48).
+// ----------------------------------------------------------------------------------
+__device__ __forceinline__ float row16_sum(float v) {  // all-reduce over the 16 lanes of a DPP row
+  v += dpp_term<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v += dpp_term<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+  v += dpp_term<0x141, 0xf>(v);  // row_half_mirror
+  v += dpp_term<0x140, 0xf>(v);  // row_mirror
+  return v;
+}
+
+template <int NB, int NW, int W, int I>
+__host__ __device__ constexpr bool cg_row_has_offdiag() {
+  for (int J = I + 1; J < NB; ++J)
+    if (tile_of<NB>(I, J) % NW == W) return true;
+  return false;
+}
+template <int NB, int NW, int W, int I>
+__host__ __device__ constexpr bool cg_row_has_any() {
+  for (int J = I; J < NB; ++J)
+    if (tile_of<NB>(I, J) % NW == W) return true;
+  return false;
+}
+
+template <int NB, int NW, int W>
+__device__ __forceinline__ void cg_wave_core(f32x4 (&T)[(NB * (NB + 1) / 2 + NW - 1) / NW], float* smem,
+                                             const KernelArgs& a, int f, int row, int rowlen, int lane) {
+  const int c = lane & 15, g = lane >> 4;
+  auto bperm = [](int addr, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
+  };
+  const float reg = (float)rowlen * a.lambda;  // lambda * n_u on the diagonal (als.cu:545-557)
+  static_for<NB>([&](auto ic) {
+    constexpr int t = tile_of<NB>(decltype(ic)::value, decltype(ic)::value);
+    if constexpr (t % NW == W) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = T[t / NW][r] + reg;
+        T[t / NW][r] = (4 * g + r == c) ? d : T[t / NW][r];
+      }
+    }
+  });
+  bool live[NB];  // this lane's element of block J exists (16 J + c < f)
+  static_for<NB>([&](auto jc) { live[decltype(jc)::value] = 16 * decltype(jc)::value + c < f; });
+  float* xch = smem;  // NW > 1: [wave][NB][16] partial vectors
+  const int sel_addr = 4 * (16 * (c >> 2) + c);  // lane (c >> 2, c): holds element c of a row-layout block after (1)
+  const int row_addr = 4 * (20 * g);             // + 4 r: lane (g, 4 g + r) holds v[16 I + 4 g + r] in the column layout
+  // row layout (lanes of group g, registers r: element 4 g + r, the same in all 16 lanes) -> column layout
+  const bool cr1 = (c & 3) == 1, cr2 = (c & 3) == 2, cr3 = (c & 3) == 3;
+  auto to_col = [&](const float (&R)[4]) {
+    float w = R[0];  // flat selects (v_cndmask): a nested ?: becomes exec-mask branches
+    w = cr1 ? R[1] : w;
+    w = cr2 ? R[2] : w;
+    w = cr3 ? R[3] : w;
+    return bperm(sel_addr, w);
+  };
+  // sum of the waves' partial column-layout vectors (NW > 1)
+  auto combine = [&](float (&y)[NB]) {
+    if constexpr (NW > 1) {
+      __syncthreads();  // the previous exchange has been read
+      if (g == 0) {
+        static_for<NB>([&](auto jc) { xch[(W * NB + decltype(jc)::value) * 16 + c] = y[decltype(jc)::value]; });
+      }
+      __syncthreads();
+      static_for<NB>([&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        float t = 0.f;
+        static_for<NW>([&](auto wc) { t += xch[(decltype(wc)::value * NB + J) * 16 + c]; });  // same order in every wave
+        y[J] = t;
+      });
+    }
+  };
+  // ---- right-hand side: column f of the last tile column, b[16 I + i] = T(I, NB - 1)[i][f - 16 (NB - 1)]
+  float b[NB];
+  {
+    const int cf = f - 16 * (NB - 1);
+    static_for<NB>([&](auto ic) {
+      constexpr int I = decltype(ic)::value;
+      constexpr int t = tile_of<NB>(I, NB - 1);
+      b[I] = 0.f;
+      if constexpr (t % NW == W) {
+        float R[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) R[r] = bperm(4 * (16 * g + cf), T[t / NW][r]);  // lane (g, cf) over its row
+        b[I] = to_col(R);
+      }
+    });
+    combine(b);
+    static_for<NB>([&](auto jc) { b[decltype(jc)::value] = live[decltype(jc)::value] ? b[decltype(jc)::value] : 0.f; });
+  }
+  // ---- y = A v
+  auto matvec = [&](const float (&v)[NB], float (&y)[NB]) {
+    float ca[NB];
+    static_for<NB>([&](auto jc) {
+      ca[decltype(jc)::value] = 0.f;
+      y[decltype(jc)::value] = 0.f;
+    });
+    static_for<NB>([&](auto ic) {
+      constexpr int I = decltype(ic)::value;
+      if constexpr (cg_row_has_any<NB, NW, W, I>()) {
+        float pr[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (cg_row_has_offdiag<NB, NW, W, I>()) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pr[r] = bperm(row_addr + 4 * r, v[I]);
+        }
+        float ra[4] = {0.f, 0.f, 0.f, 0.f};
+        static_for<NB>([&](auto jc) {
+          constexpr int J = decltype(jc)::value;
+          if constexpr (J >= I && tile_of<NB>(I, J) % NW == W) {
+            constexpr int s = tile_of<NB>(I, J) / NW;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ra[r] = fmaf(T[s][r], v[J], ra[r]);
+            if constexpr (J > I) {
+              float t = ca[J];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) t = fmaf(T[s][r], pr[r], t);
+              ca[J] = t;
+            }
+          }
+        });
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ra[r] = row16_sum(ra[r]);
+        y[I] = to_col(ra);
+      }
+    });
+    static_for<NB>([&](auto jc) {
+      constexpr int J = decltype(jc)::value;
+      float t = ca[J];
+      t += bperm(4 * (lane ^ 16), t);
+      t += bperm(4 * (lane ^ 32), t);
+      y[J] += t;
+    });
+    combine(y);
+    static_for<NB>([&](auto jc) { y[decltype(jc)::value] = live[decltype(jc)::value] ? y[decltype(jc)::value] : 0.f; });
+  };
+  auto dot = [&](const float (&u)[NB], const float (&v)[NB]) {
+    float t = 0.f;
+    static_for<NB>([&](auto jc) { t = fmaf(u[decltype(jc)::value], v[decltype(jc)::value], t); });
+    return row16_sum(t);
+  };
+  // ---- CG (cg.cu:36-231)
+  float* xg = a.update + (size_t)row * f;
+  float x[NB], r[NB], p[NB], ap[NB];
+  static_for<NB>([&](auto jc) {
+    constexpr int J = decltype(jc)::value;
+    const float xv = xg[live[J] ? 16 * J + c : 0];  // warm start (cg.cu:48); dead lanes read element 0 and drop it
+    x[J] = live[J] ? xv : 0.f;
+  });
+  matvec(x, ap);
+  static_for<NB>([&](auto jc) {
+    constexpr int J = decltype(jc)::value;
+    r[J] = b[J] - ap[J];
+    p[J] = r[J];
+  });
+  float rsold = dot(r, r);
+  for (int iter = 0; iter < a.cg_iters; ++iter) {
+    matvec(p, ap);
+    const float pap = dot(p, ap);
+    const float alpha = rsold / pap;
+    static_for<NB>([&](auto jc) {
+      constexpr int J = decltype(jc)::value;
+      x[J] = fmaf(alpha, p[J], x[J]);
+      r[J] = fmaf(-alpha, ap[J], r[J]);
+    });
+    const float rsnew = dot(r, r);
+    if ((double)rsnew < 1e-4) break;  // CG_ERROR (cg.cu:31,195); uniform: every wave computes the same bits
+    const float beta = rsnew / rsold;
+    rsold = rsnew;
+    static_for<NB>([&](auto jc) {
+      constexpr int J = decltype(jc)::value;
+      p[J] = fmaf(beta, p[J], r[J]);
+    });
+  }
+  if (W == 0 && g == 0) {
+    static_for<NB>([&](auto jc) {
+      constexpr int J = decltype(jc)::value;
+      if (live[J]) xg[16 * J + c] = x[J];
+    });
+  }
+}
+
+// tiles of wave W from the dumped slots (summed in slot order), then the CG
+template <int NB, int NW, int W>
+__device__ __forceinline__ void cg_wave_body(float* smem, const KernelArgs& a, int row, int slot0, int nslots,
+                                             int rowlen, int lane) {
+  constexpr int NT = NB * (NB + 1) / 2;
+  constexpr int TPW = (NT + NW - 1) / NW;
+  f32x4 T[TPW];
+#pragma unroll
+  for (int s = 0; s < TPW; ++s) T[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int sl = 0; sl < nslots; ++sl) {
+    const float* part = a.part + (size_t)(slot0 + sl) * NT * 256;
+    static_for<TPW>([&](auto sc) {
+      constexpr int t = W + NW * decltype(sc)::value;
+      if constexpr (t < NT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[decltype(sc)::value][r] += part[((size_t)t * 4 + r) * 64 + lane];
+      }
+    });
+  }
+  cg_wave_core<NB, NW, W>(T, smem, a, a.f, row, rowlen, lane);
+}
+
+template <int NB, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void als_wave_cg_kernel(const KernelArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63;
+  const int mr = blockIdx.x;
+  const int row = a.mrow_row[mr];
+  const int slot0 = a.dense_slots ? mr : a.mrow_slot0[mr];
+  const int nslots = a.dense_slots ? 1 : a.mrow_nslots[mr];
+  const int rowlen = a.mrow_rowlen[mr];
+  if constexpr (NW == 1) {
+    cg_wave_body<NB, 1, 0>(smem, a, row, slot0, nslots, rowlen, lane);
+  } else if constexpr (NW == 2) {
+    if ((threadIdx.x >> 6) == 0)
+      cg_wave_body<NB, NW, 0>(smem, a, row, slot0, nslots, rowlen, lane);
+    else
+      cg_wave_body<NB, NW, 1>(smem, a, row, slot0, nslots, rowlen, lane);
+  } else {
+    static_assert(NW == 4, "1, 2 or 4 waves per system");
+    switch (threadIdx.x >> 6) {
+      case 0: cg_wave_body<NB, NW, 0>(smem, a, row, slot0, nslots, rowlen, lane); break;
+      case 1: cg_wave_body<NB, NW, 1>(smem, a, row, slot0, nslots, rowlen, lane); break;
+      case 2: cg_wave_body<NB, NW, 2>(smem, a, row, slot0, nslots, rowlen, lane); break;
+      default: cg_wave_body<NB, NW, 3>(smem, a, row, slot0, nslots, rowlen, lane); break;
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------
 // Kernel: one 64-thread workgroup (= one wave) per plan item.  FC != 0: f known at compile time.
 // ----------------------------------------------------------------------------------
 #if CUMF_WAVE_VARIANT & 8
@@ -665,9 +911,187 @@ __global__ __launch_bounds__(64, CUMF_WAVE_MIN_WAVES) void als_wave_kernel(const
       wave_tiles_to_global<NB>(acc, reinterpret_cast<_Float16*>(a.tt) + off, rhs, f, reg, lane);
     else
       wave_tiles_to_global<NB>(acc, a.tt + off, rhs, f, reg, lane);
+  } else if constexpr (MODE == kModeCG) {
+    cg_wave_core<NB, 1, 0>(acc, smem, a, f, row, rowlen, lane);  // the reference's default solver (als.cu:28)
   } else {
     lu_wave<NB, FC>(acc, smem, f, reg, a.update + (size_t)row * f, lane);
   }
+}
+
+// ----------------------------------------------------------------------------------
+// Large systems (NB = 8 .. 13, f = 112 .. 207): NW = 2 waves per item.  The upper-triangular tiles
+// are dealt to the two waves (tile t belongs to wave t % 2: 46 / 45 tiles at NB = 13), both waves
+// need every feature block of the stage as an operand, so the 8 NB gather chunks are shared: each
+// wave issues the LDS-DMA loads of its half of the chunks, two workgroup barriers per stage make the
+// hand-over (all chunks landed / all chunks read), and each wave splits all blocks for itself
+// (redundant VALU: the alternative is a third pass through LDS).  No solve in this kernel: every
+// item dumps its tiles (plan slots for chunk items, dense slots for whole rows) and
+// als_reduce_kernel finishes the rows (LU, CG for f <= 128, or the materialised f x f Gram for
+// cg_global_kernel) -- the reference's own data flow (als.cu:782-831).
+// ----------------------------------------------------------------------------------
+template <int NB, int NW, int W>
+__device__ __forceinline__ void multi_body(float* smem, const KernelArgs& a, long long begin, int len, int slot,
+                                           int lane) {
+  constexpr int NT = NB * (NB + 1) / 2;
+  constexpr int TPW = (NT + NW - 1) / NW;
+  const int f = a.f;
+  f32x4 acc[TPW];
+#pragma unroll
+  for (int s = 0; s < TPW; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nst = (len + kWaveStage - 1) / kWaveStage;
+  if (nst > 0) {
+    WaveGather<NB> wg;
+    wg.init(a, f, begin, len, lane);
+    WaveStage<NB> R;
+    Planes<NB> P;
+    lds_float_ptr lds = (lds_float_ptr)smem;
+    const float* lds_lane = smem + lane;
+    using gptr = const __attribute__((address_space(1))) void*;
+    using lptr = __attribute__((address_space(3))) void*;
+    auto clamp = [&](int s) { return s < nst ? s : nst - 1; };
+    // this wave's share of the chunks of stage s (feature blocks b with b % NW == W)
+    auto issue_share = [&](int s) {
+      static_for<8>([&](auto ec) {
+        constexpr int E = decltype(ec)::value;
+        const char* row = wg.template row_ptr<false, E>(R, s);
+        static_for<NB>([&](auto bc) {
+          constexpr int B = decltype(bc)::value;
+          if constexpr (B % NW == W) {
+            constexpr int k = E * NB + B;
+            if constexpr (B + 1 < NB)
+              __builtin_amdgcn_global_load_lds((gptr)row, (lptr)(lds + 64 * k - 16 * B), 4, 64 * B, 0);
+            else
+              __builtin_amdgcn_global_load_lds((gptr)(row + wg.last_off), (lptr)(lds + 64 * k), 4, 0, 0);
+          }
+        });
+      });
+    };
+    wg.template load_idx<false>(R, 0);
+    issue_share(0);
+    wg.template load_val<false>(R, 0);
+    wg.template load_idx<false>(R, clamp(1));
+    for (int s = 0; s < nst; ++s) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's chunks have landed
+      __syncthreads();                      // ... and the partner's
+      // chunk -> registers -> planes, block by block (the raw values of one block live at a time)
+      static_for<NB>([&](auto bc) {
+        constexpr int B = decltype(bc)::value;
+        static_for<8>([&](auto ec) {
+          constexpr int E = decltype(ec)::value;
+          R.raw[B][E] = lds_lane[64 * (E * NB + B)];
+        });
+        if constexpr (B == NB - 1) static_for<8>([&](auto ec) { wg.template finish_one<decltype(ec)::value>(R); });
+        static_for<4>([&](auto vc) { split_pair<NB, B, decltype(vc)::value>(R, P); });
+      });
+      __syncthreads();  // both waves have read the chunks: the buffer may be refilled
+      issue_share(clamp(s + 1));
+      wg.template load_val<false>(R, clamp(s + 1));
+      wg.template load_idx<false>(R, clamp(s + 2));
+      static_for<6>([&](auto pc) {
+        constexpr int PROD = decltype(pc)::value;
+        static_for<TPW>([&](auto sc) {
+          constexpr int t = W + NW * decltype(sc)::value;
+          if constexpr (t < NT) {
+            constexpr int I = tile_I<NB>(t), J = tile_J<NB>(t), sl = decltype(sc)::value;
+            if constexpr (PROD == 0) acc[sl] = mfma_bf16(P.l[I], P.h[J], acc[sl]);
+            if constexpr (PROD == 1) acc[sl] = mfma_bf16(P.h[I], P.l[J], acc[sl]);
+            if constexpr (PROD == 2) acc[sl] = mfma_bf16(P.m[I], P.m[J], acc[sl]);
+            if constexpr (PROD == 3) acc[sl] = mfma_bf16(P.m[I], P.h[J], acc[sl]);
+            if constexpr (PROD == 4) acc[sl] = mfma_bf16(P.h[I], P.m[J], acc[sl]);
+            if constexpr (PROD == 5) acc[sl] = mfma_bf16(P.h[I], P.h[J], acc[sl]);
+          }
+        });
+      });
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // the last (unused) prefetch must land before the workgroup exits
+  }
+  float* part = a.part + (size_t)slot * NT * 256;
+  static_for<TPW>([&](auto sc) {
+    constexpr int t = W + NW * decltype(sc)::value;
+    if constexpr (t < NT) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[((size_t)t * 4 + r) * 64 + lane] = acc[decltype(sc)::value][r];
+    }
+  });
+}
+
+template <int NB, int NW>
+__global__ __launch_bounds__(64 * NW, NB >= 10 ? 1 : 2) void als_wave_multi_kernel(const KernelArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x;
+  const long long begin = a.item_begin[item];
+  const int len = a.item_len[item];
+  const int slot = a.dense_slots ? item : a.item_slot[item];
+  static_assert(NW == 2, "two waves per item");
+  if ((threadIdx.x >> 6) == 0)
+    multi_body<NB, NW, 0>(smem, a, begin, len, slot, lane);
+  else
+    multi_body<NB, NW, 1>(smem, a, begin, len, slot, lane);
+}
+
+// ----------------------------------------------------------------------------------
+// Solver kernel on dumped tiles: one wave per row sums the row's slots (a fixed, deterministic order)
+// into a full tile set and runs the single-wave LU above.  At f = 200 that is 91 tiles = 364
+// accumulator registers of a 512-register wave -- against the 4-wave lu_solve_mfma whose 95 KB row
+// store leaves ONE workgroup per CU (measured: 121 ms per Netflix iteration at f = 200).
+// ----------------------------------------------------------------------------------
+template <int NB, int MODE>
+__global__ __launch_bounds__(64, NB >= 10 ? 1 : 2) void als_wave_solve_kernel(const KernelArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NT = NB * (NB + 1) / 2;
+  const int lane = threadIdx.x;
+  const int mr = blockIdx.x;
+  const int row = a.mrow_row[mr];
+  const int slot0 = a.dense_slots ? mr : a.mrow_slot0[mr];
+  const int nslots = a.dense_slots ? 1 : a.mrow_nslots[mr];
+  const int rowlen = a.mrow_rowlen[mr];
+  const int f = a.f;
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int sl = 0; sl < nslots; ++sl) {
+    const float* part = a.part + (size_t)(slot0 + sl) * NT * 256;
+    static_for<NT>([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[t][r] += part[((size_t)t * 4 + r) * 64 + lane];
+    });
+  }
+  const float reg = (float)rowlen * a.lambda;  // als.cu:547
+  if constexpr (MODE == kModeMaterialize) {
+    const size_t off = (size_t)(row - a.row_begin) * f * f;
+    float* rhs = a.rhs ? a.rhs + (size_t)(row - a.row_begin) * f : nullptr;
+    if (a.tt_half)
+      wave_tiles_to_global<NB>(acc, reinterpret_cast<_Float16*>(a.tt) + off, rhs, f, reg, lane);
+    else
+      wave_tiles_to_global<NB>(acc, a.tt + off, rhs, f, reg, lane);
+  } else {
+    lu_wave<NB, 0>(acc, smem, f, reg, a.update + (size_t)row * f, lane);
+  }
+}
+
+template <int NB>
+hipError_t wave_solve_launch(const KernelArgs& a, int mode, long n_rows, hipStream_t stream);
+template <>
+hipError_t wave_solve_launch<CUMF_WAVE_NB>(const KernelArgs& a, int mode, long n_rows, hipStream_t stream) {
+  if (n_rows <= 0) return hipSuccess;
+  if (mode == kModeMaterialize) {
+    hipLaunchKernelGGL((als_wave_solve_kernel<CUMF_WAVE_NB, kModeMaterialize>), dim3((unsigned)n_rows), dim3(64), 0,
+                       stream, a);
+  } else if (mode == kModeLU) {
+    const size_t lds = wave_lu_lds_floats<CUMF_WAVE_NB>(a.f) * sizeof(float);
+    hipLaunchKernelGGL((als_wave_solve_kernel<CUMF_WAVE_NB, kModeLU>), dim3((unsigned)n_rows), dim3(64), lds, stream, a);
+  } else if (mode == kModeCG) {
+    // the tiles are VALU operands (VGPRs only): 91 tiles at NB = 13 = four waves x 23 tiles next to the five
+    // vectors, at two waves per SIMD
+    constexpr int NW = CUMF_WAVE_NB >= 10 ? 4 : 1;
+    const size_t lds = NW > 1 ? (size_t)NW * CUMF_WAVE_NB * 16 * sizeof(float) : 0;
+    hipLaunchKernelGGL((als_wave_cg_kernel<CUMF_WAVE_NB, NW>), dim3((unsigned)n_rows), dim3(64 * NW), lds, stream, a);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
 }
 
 // ----------------------------------------------------------------------------------
@@ -679,6 +1103,8 @@ static hipError_t launch_wave_fc(const KernelArgs& a, int mode, long n_items, hi
   if (mode == kModeMaterialize) {
     hipLaunchKernelGGL((als_wave_kernel<NB, kModeMaterialize, FC>), dim3((unsigned)n_items), dim3(64), stage_lds, stream,
                        a);
+  } else if (mode == kModeCG) {
+    hipLaunchKernelGGL((als_wave_kernel<NB, kModeCG, FC>), dim3((unsigned)n_items), dim3(64), stage_lds, stream, a);
   } else {
     const size_t lu_lds = wave_lu_lds_floats<NB>(a.f) * sizeof(float);
     const size_t lds = lu_lds > stage_lds ? lu_lds : stage_lds;
@@ -692,9 +1118,6 @@ static hipError_t launch_wave_fc(const KernelArgs& a, int mode, long n_items, hi
   return hipGetLastError();
 }
 
-#ifndef CUMF_WAVE_NB
-#error "compile with -DCUMF_WAVE_NB=<feature blocks>"
-#endif
 #ifndef CUMF_WAVE_VARIANT
 #define CUMF_WAVE_VARIANT 0  // experiment switches (tools/wave_variants.sh)
 #endif
@@ -704,12 +1127,20 @@ hipError_t wave_item_launch(const KernelArgs& a, int mode, long n_items, hipStre
 template <>
 hipError_t wave_item_launch<CUMF_WAVE_NB>(const KernelArgs& a, int mode, long n_items, hipStream_t stream) {
   if (n_items <= 0) return hipSuccess;
-  if (mode != kModeMaterialize && mode != kModeLU) return hipErrorInvalidValue;
+#if CUMF_WAVE_NB > 7
+  // dump-only kernel, two waves per item (every item must have a slot)
+  (void)mode;
+  const size_t lds = wave_stage_lds_floats<CUMF_WAVE_NB>() * sizeof(float);
+  hipLaunchKernelGGL((als_wave_multi_kernel<CUMF_WAVE_NB, 2>), dim3((unsigned)n_items), dim3(128), lds, stream, a);
+  return hipGetLastError();
+#else
+  if (mode != kModeMaterialize && mode != kModeLU && mode != kModeCG) return hipErrorInvalidValue;
 #if CUMF_WAVE_NB == 7 && !(CUMF_WAVE_VARIANT & 2)
   // the reference's own specialisation: get_hermitian100 for f == 100 (als.cu:788-817)
   if (a.f == 100) return launch_wave_fc<7, 100>(a, mode, n_items, stream);
 #endif
   return launch_wave_fc<CUMF_WAVE_NB, 0>(a, mode, n_items, stream);
+#endif
 }
 
 }  // namespace cumf

@@ -80,6 +80,8 @@ int cumf_plan_info(const cumf_plan_t* plan, long info[4]);
  * factors being solved (rows x f), read as the CG warm start and overwritten.
  * `gather` must be smaller than 4 GiB (32-bit byte offsets in the gather: 10.7 M rows at f = 100).
  */
+/* 1 when cumf_als_update_fused can handle (f, solver) in the current gram mode. */
+int cumf_fused_available(int f, int solver);
 int cumf_als_update_fused(const cumf_plan_t* plan, const int* colidx, const float* val,
                           const float* gather, float* update, int f, float lambda, int solver,
                           int cg_iters, void* stream);
