@@ -703,12 +703,117 @@ __host__ __device__ constexpr int lu_diag_slot(int W, int Ip) {
   return 0;
 }
 
+// LDS of lu_solve_mfma (round 2): [exchange: 2 x 4 panel rows x 16 NB][window: 16 NB rows x 17]
+// [pivot reciprocals][2 x 16 multipliers][16 zeros].  f = 200: 24 KB instead of the 95 KB packed row
+// store of round 1 (one workgroup per CU); f = 100: 12.6 KB instead of 29.5 KB.
+template <int NB>
+struct LuLds {
+  static constexpr int kXRow = 16 * NB;            // one published panel row
+  static constexpr int kX = 2 * 4 * kXRow;         // double-buffered by panel parity
+  static constexpr int kPitch = 17;                // window pitch (odd: lane = row reads are conflict-free)
+  static constexpr int kT = 16 * NB * kPitch;
+};
+
+// LDS floats of the fused LU of NB feature blocks: lu_solve_mfma (NB >= 7) or the thread-grid
+// lu_solve_reg on the packed row store.
+template <int NB>
+__host__ __device__ constexpr size_t lu_fused_lds_floats(int f) {
+  return lu_on_accumulators(NB) ? (size_t)LuLds<NB>::kX + LuLds<NB>::kT + ((f + 3) & ~3) + 48 : lu_lds_floats(NB, f);
+}
+
+// Back substitution U x = y by the workgroup, straight from the accumulator tiles of the four roles
+// through the LDS window (same recurrence as back_substitute_zeroed): per 16-pivot block column kb every
+// role writes its tiles (I, kb), I <= kb, to the window (entries at and left of the diagonal as zeros),
+// barrier, wave 0 (lane i = rows i, i + 64, ...) reads the 16 entries of its rows and runs the 16 steps,
+// barrier.  2 (NB) barriers instead of a 95 KB row store.
+template <int NB, int W, int NQ>
+__device__ __forceinline__ void back_substitute_tiles_wg(const f32x4 (&acc)[Geo<NB>::TPW], float* __restrict__ T,
+                                                         const float* __restrict__ rdiag,
+                                                         const float* __restrict__ zpad, int f,
+                                                         float* __restrict__ x_global, int lane) {
+  constexpr int NT = Geo<NB>::NT, TPW = Geo<NB>::TPW, P = LuLds<NB>::kPitch;
+  const int c = lane & 15, g = lane >> 4;
+  const int top = f - 1;
+  float z[NQ], rdl[NQ];
+  const float* rowp[NQ];
+  int ib[NQ];
+  if constexpr (W == 0) {
+    static_for<NQ>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      const int i = lane + 64 * q;
+      const int ic = i < f ? i : f - 1;
+      ib[q] = i < f ? (i >> 4) : 1 << 20;  // rows past f never take part
+      rowp[q] = T + ic * P;
+      rdl[q] = i < f ? rdiag[ic] : 0.f;
+      z[q] = 0.f;
+    });
+  }
+  static_for<NB>([&](auto bc) {
+    constexpr int kb = NB - 1 - decltype(bc)::value;
+    constexpr int Q = kb >> 2;  // pivots of this block live in z[Q]
+    // this role's tiles of block column kb -> window
+    static_for<TPW>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      constexpr int t = Geo<NB>::tile(W, s);
+      if constexpr (t < NT) {
+        if constexpr (tile_J<NB>(t) == kb) {
+          constexpr int I = tile_I<NB>(t);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = acc[s][r];
+            if constexpr (I == kb) v = (c > 4 * g + r) ? v : 0.f;
+            T[(16 * I + 4 * g + r) * P + c] = v;
+          }
+        }
+      }
+    });
+    __syncthreads();
+    if constexpr (W == 0 && Q < NQ) {
+      if constexpr (kb == NB - 1) {  // y = column f of the last block column
+        static_for<NQ>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          z[q] = rowp[q][f - 16 * (NB - 1)] * rdl[q];
+        });
+      }
+      if (16 * kb <= top) {  // uniform: the last block column may hold nothing but y
+        float col[16][Q + 1];
+        static_for<Q + 1>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          const float* base = (ib[q] > kb) ? zpad : rowp[q];
+          static_for<16>([&](auto jc) { col[decltype(jc)::value][q] = base[decltype(jc)::value]; });
+        });
+        static_for<16>([&](auto jc) {
+          constexpr int j = 15 - decltype(jc)::value;
+          const int k = 16 * kb + j;
+          if (k <= top) {  // uniform; only the last block can be short
+            const float xk = __builtin_bit_cast(
+                float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z[Q]), k & 63));
+            static_for<Q + 1>([&](auto qc) {
+              constexpr int q = decltype(qc)::value;
+              z[q] = fmaf(-(col[j][q] * rdl[q]), xk, z[q]);
+            });
+          }
+        });
+      }
+    }
+    if constexpr (kb > 0) __syncthreads();  // the window is rewritten for the next block column
+  });
+  if constexpr (W == 0) {
+    static_for<NQ>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      if (lane + 64 * q < f) x_global[lane + 64 * q] = z[q];
+    });
+  }
+}
+
 template <int NB, int W>
-__device__ __forceinline__ void lu_solve_mfma(f32x4 (&acc)[Geo<NB>::TPW], float* __restrict__ U,
-                                              float* __restrict__ rdiag, int f, float reg,
+__device__ __forceinline__ void lu_solve_mfma(f32x4 (&acc)[Geo<NB>::TPW], float* __restrict__ lds, int f, float reg,
                                               float* __restrict__ x_global, int tid) {
   constexpr int NT = Geo<NB>::NT, TPW = Geo<NB>::TPW;
   const int lane = tid & 63, c = lane & 15, kk = lane >> 4;
+  float* X = lds;                                 // published raw panel rows, [parity][r][16 NB]
+  float* Twin = lds + LuLds<NB>::kX;              // back-substitution window
+  float* rdiag = Twin + LuLds<NB>::kT;            // pivot reciprocals
   // lambda * n_u on the diagonal (als.cu:545-557)
   static_for<TPW>([&](auto sc) {
     constexpr int s = decltype(sc)::value;
@@ -726,24 +831,6 @@ __device__ __forceinline__ void lu_solve_mfma(f32x4 (&acc)[Geo<NB>::TPW], float*
   if constexpr (W == 0) {
     if (lane < 16) zpad[lane] = 0.f;
   }
-  float fin[NB];  // wave 0: eliminated rows of the previous panel at this lane's (row kk, columns 16 b + c)
-  int fin_p0 = -1;
-  auto write_fin = [&]() {  // rows fin_p0 + kk, blocks from the panel's own block row on
-    if constexpr (W == 0) {
-      if (fin_p0 >= 0 && fin_p0 + kk < f) {
-        float* w = U + lu_row_off<NB>(fin_p0 + kk) + c;
-        const int b0 = fin_p0 >> 4;
-        static_for<NB>([&](auto bc) {
-          constexpr int b = decltype(bc)::value;
-          // inside the row's own block the entries at or left of the diagonal are dead: store zeros
-          // there, so that the back substitution needs no triangle mask
-          const float v = (b > b0 || c > ((fin_p0 + kk) & 15)) ? fin[b] : 0.f;
-          if (b >= b0 && (b < NB - 1 || 16 * b + c <= f)) w[16 * b] = v;
-        });
-      }
-    }
-  };
-
   static_for<NB>([&](auto ipc) {
     constexpr int Ip = decltype(ipc)::value;
     for (int q = 0; q < 4; ++q) {
@@ -759,10 +846,10 @@ __device__ __forceinline__ void lu_solve_mfma(f32x4 (&acc)[Geo<NB>::TPW], float*
         if constexpr (t < NT) {
           if constexpr (tile_I<NB>(t) == Ip) {
             constexpr int J = tile_J<NB>(t);
-            if (kk == q && (J < NB - 1 || 16 * J + c <= f)) {
+            if (kk == q) {
+              float* xp = X + ((p0 >> 2) & 1) * 4 * LuLds<NB>::kXRow + 16 * J + c;
 #pragma unroll
-              for (int r = 0; r < 4; ++r)
-                if (p0 + r < f) U[lu_row_off<NB>(p0 + r) + 16 * J + c] = acc[s][r];
+              for (int r = 0; r < 4; ++r) xp[r * LuLds<NB>::kXRow] = acc[s][r];
             }
           }
         }
@@ -822,12 +909,11 @@ __device__ __forceinline__ void lu_solve_mfma(f32x4 (&acc)[Geo<NB>::TPW], float*
         if (c == 4 && vk) rdiag[p0 + kk] = rpk;
       }
       __syncthreads();
-      // 4. (of the previous panel) final rows into the store
-      write_fin();
       if constexpr (lu_wave_live<NB>(W, Ip)) {
-      const float* r0p = U + lu_row_off<NB>(p0);
-      const float* r1p = U + lu_row_off<NB>(p0 + 1 < f ? p0 + 1 : p0);
-      const float* r2p = U + lu_row_off<NB>(p0 + 2 < f ? p0 + 2 : p0);
+      const float* xb = X + ((p0 >> 2) & 1) * 4 * LuLds<NB>::kXRow;
+      const float* r0p = xb;
+      const float* r1p = xb + LuLds<NB>::kXRow;
+      const float* r2p = xb + 2 * LuLds<NB>::kXRow;
       if constexpr (W != OWNER) {
         const f32x4 line = *reinterpret_cast<const f32x4*>(tab + 4 * kk);
         c0 = line[0];
@@ -836,7 +922,7 @@ __device__ __forceinline__ void lu_solve_mfma(f32x4 (&acc)[Geo<NB>::TPW], float*
         nrp = line[3];
       }
       // 2b. eliminated panel row of this lane group at every live block: three FMAs per block
-      const float* rkp = U + lu_row_off<NB>(vk ? p0 + kk : p0);
+      const float* rkp = xb + kk * LuLds<NB>::kXRow;
       float ub[NB];
       static_for<NB>([&](auto bc) {
         constexpr int b = decltype(bc)::value;
@@ -869,22 +955,13 @@ __device__ __forceinline__ void lu_solve_mfma(f32x4 (&acc)[Geo<NB>::TPW], float*
           }
         }
       });
-      // 4. remember the eliminated rows
-      if constexpr (W == 0) {
-        static_for<NB>([&](auto bc) {
-          constexpr int b = decltype(bc)::value;
-          if constexpr (b >= Ip) fin[b] = ub[b];
-        });
-        fin_p0 = p0;
-      }
       }  // lu_wave_live
     }
   });
-  __syncthreads();
-  write_fin();
-  __syncthreads();
+  // the eliminated rows stay in the accumulators (the masked update leaves rows at and above a pivot alone)
+  __syncthreads();  // rdiag is complete
 #if !(CUMF_VARIANT_A & 8)
-  if constexpr (W == 0) back_substitute_zeroed<NB, (16 * NB + 63) / 64>(U, f, rdiag, zpad, x_global, lane);
+  back_substitute_tiles_wg<NB, W, (16 * NB + 63) / 64>(acc, Twin, rdiag, zpad, f, x_global, lane);
 #endif
 }
 
@@ -947,8 +1024,7 @@ template <int NB, int MODE, int W>
 __device__ __forceinline__ void finish_row(f32x4 (&acc)[Geo<NB>::TPW], float* smem, const KernelArgs& a, int row,
                                            int rowlen, int tid) {
   if constexpr (MODE == kModeLU && lu_on_accumulators(NB)) {
-    lu_solve_mfma<NB, W>(acc, smem, smem + lu_packed_floats(NB), a.f, (float)rowlen * a.lambda,
-                         a.update + (size_t)row * a.f, tid);
+    lu_solve_mfma<NB, W>(acc, smem, a.f, (float)rowlen * a.lambda, a.update + (size_t)row * a.f, tid);
   } else {
     dump_row<NB, MODE, W>(acc, smem, a, row, rowlen, tid & 63);
   }
@@ -1372,7 +1448,7 @@ static hipError_t launch_nb(const KernelArgs& a, long n_items, long n_mrows, hip
   const size_t stage_floats = (2 * (size_t)kStage + 8) * Geo<NB>::LD;  // + read-ahead pad of mma_stage
   size_t floats = stage_floats;
   if (MODE != kModeMaterialize) {
-    const size_t solve = MODE == kModeLU ? lu_lds_floats(NB, a.f) : solve_lds_floats(a.f, MODE);
+    const size_t solve = MODE == kModeLU ? lu_fused_lds_floats<NB>(a.f) : solve_lds_floats(a.f, MODE);
     floats = floats > solve ? floats : solve;
   }
   static const size_t lds_pad = getenv("CUMF_ALS_LDS_PAD") ? (size_t)atol(getenv("CUMF_ALS_LDS_PAD")) : 0;  // occupancy experiments
@@ -1483,7 +1559,7 @@ static hipError_t launch_reduce_only(const KernelArgs& a, int mode, long n_mrows
       return hipErrorInvalidValue;
     }
   } else {
-    const size_t lds = lu_lds_floats(NB, a.f) * sizeof(float);
+    const size_t lds = lu_fused_lds_floats<NB>(a.f) * sizeof(float);
     if (lds > 64 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(als_reduce_kernel<NB, kModeLU>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
