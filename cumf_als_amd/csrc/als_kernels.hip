@@ -1597,7 +1597,19 @@ static hipError_t launch_batched_nb(const KernelArgs& a0, int mode, const PlanLi
     e = launch_reduce_only<NB>(a0, mode, L.n_mrows, stream);
     if (e != hipSuccess) return e;
   }
-  // 2. whole rows, in batches of part2_rows dense slots
+  // 2. whole rows.  CG: solved by the two waves that formed the Gram, in one launch
+  if (mode == kModeCG) {
+    if (L.n_witems <= 0) return hipSuccess;
+    KernelArgs a = a0;
+    a.item_row = L.w_row;
+    a.item_begin = L.w_begin;
+    a.item_len = L.w_len;
+    a.item_rowlen = L.w_rowlen;
+    a.item_slot = nullptr;  // no slots: nothing is dumped
+    a.dense_slots = 0;
+    return wave_item_launch<NB>(a, kModeCG, L.n_witems, stream);
+  }
+  // LU / materialise: in batches of part2_rows dense slots
   for (long w0 = 0; w0 < L.n_witems; w0 += L.part2_rows) {
     const long cnt = L.n_witems - w0 < L.part2_rows ? L.n_witems - w0 : L.part2_rows;
     KernelArgs a = a0;

@@ -249,11 +249,11 @@ extern "C" int cumf_plan_info(const cumf_plan_t* p, long info[4]) {
 namespace {
 
 // Dense-slot tile buffer of the batched path: at most 2 GiB (74 898 systems at f = 100), allocated on
-// first use and kept with the plan.
-int plan_lists(const cumf_plan_t* cp, PlanLists* out) {
+// first use and kept with the plan.  The CG path solves whole rows inside the Gram kernel and needs none.
+int plan_lists(const cumf_plan_t* cp, PlanLists* out, bool need_tiles = true) {
   cumf_plan* p = const_cast<cumf_plan*>(cp);
   const size_t tile_bytes = (size_t)p->nb * (p->nb + 1) / 2 * 256 * sizeof(float);
-  if (!p->d_part2 && p->n_witems > 0) {
+  if (need_tiles && !p->d_part2 && p->n_witems > 0) {
     long rows = (long)std::min<size_t>((size_t)p->n_witems, ((size_t)2 << 30) / tile_bytes);
     if (rows < 1) rows = 1;
     CUMF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p->d_part2), (size_t)rows * tile_bytes));
@@ -324,7 +324,7 @@ extern "C" int cumf_als_update_fused(const cumf_plan_t* p, const int* colidx, co
   (void)long_rows;
   const bool batched = wave_batched_path(f, mode);
   if (batched) {
-    const int rc = plan_lists(p, &lists);
+    const int rc = plan_lists(p, &lists, mode != kModeCG);
     if (rc) return rc;
   }
   CUMF_HIP_CHECK(launch_half_iteration(a, mode, p->n_items, p->n_mrows, static_cast<hipStream_t>(stream),

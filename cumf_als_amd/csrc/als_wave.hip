@@ -70,6 +70,20 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 }
 __device__ __forceinline__ float bf16_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+// x - (low / high bf16 of p), exact whenever the difference is representable (it is for the residuals of
+// the split): one v_dot2c_f32_bf16 (x += p.lo * s.lo + p.hi * s.hi with s = (-1, 0) / (0, -1)) instead of
+// unpack + subtract.  The selector pairs sit in SGPRs: as immediates the compiler emits the inline
+// constant -1.0, which the instruction does not read as the bf16 pair (tools/dot2_probe.hip).
+__device__ __forceinline__ float sub_bf16_lo(float x, unsigned p) {
+  unsigned sel;
+  asm("s_mov_b32 %0, 0xbf80" : "=s"(sel));
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, p), __builtin_bit_cast(bf16x2, sel), x, false);
+}
+__device__ __forceinline__ float sub_bf16_hi(float x, unsigned p) {
+  unsigned sel;
+  asm("s_mov_b32 %0, 0xbf800000" : "=s"(sel));
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, p), __builtin_bit_cast(bf16x2, sel), x, false);
+}
 
 __device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
@@ -244,20 +258,18 @@ __device__ __forceinline__ void split_micro(const WaveStage<NB>& st, Planes<NB>&
     x.b = st.raw[B][2 * V + 1];
     x.H = pack_bf16(x.a, x.b);
   } else if constexpr (STEP == 1) {
-    x.ta = bf16_lo(x.H);
-    x.tb = bf16_hi(x.H);
+    x.ra = sub_bf16_lo(x.a, x.H);
   } else if constexpr (STEP == 2) {
-    x.ra = x.a - x.ta;
-    x.rb = x.b - x.tb;
+    x.rb = sub_bf16_hi(x.b, x.H);
   } else if constexpr (STEP == 3) {
     x.M = pack_bf16(x.ra, x.rb);
   } else if constexpr (STEP == 4) {
-    x.ta = bf16_lo(x.M);
-    x.tb = bf16_hi(x.M);
+    x.ta = sub_bf16_lo(x.ra, x.M);
+    x.tb = sub_bf16_hi(x.rb, x.M);
   } else {
     P.h[B][V] = x.H;
     P.m[B][V] = x.M;
-    P.l[B][V] = pack_bf16(x.ra - x.ta, x.rb - x.tb);
+    P.l[B][V] = pack_bf16(x.ta, x.tb);
   }
 }
 template <int NB, int B, int V>
@@ -929,9 +941,9 @@ __global__ __launch_bounds__(64, CUMF_WAVE_MIN_WAVES) void als_wave_kernel(const
 // als_reduce_kernel finishes the rows (LU, CG for f <= 128, or the materialised f x f Gram for
 // cg_global_kernel) -- the reference's own data flow (als.cu:782-831).
 // ----------------------------------------------------------------------------------
-template <int NB, int NW, int W>
+template <int NB, int NW, int W, int MODE>
 __device__ __forceinline__ void multi_body(float* smem, const KernelArgs& a, long long begin, int len, int slot,
-                                           int lane) {
+                                           int row, int rowlen, int lane) {
   constexpr int NT = NB * (NB + 1) / 2;
   constexpr int TPW = (NT + NW - 1) / NW;
   const int f = a.f;
@@ -944,13 +956,15 @@ __device__ __forceinline__ void multi_body(float* smem, const KernelArgs& a, lon
     wg.init(a, f, begin, len, lane);
     WaveStage<NB> R;
     Planes<NB> P;
-    lds_float_ptr lds = (lds_float_ptr)smem;
-    const float* lds_lane = smem + lane;
     using gptr = const __attribute__((address_space(1))) void*;
     using lptr = __attribute__((address_space(3))) void*;
     auto clamp = [&](int s) { return s < nst ? s : nst - 1; };
     // this wave's share of the chunks of stage s (feature blocks b with b % NW == W)
-    auto issue_share = [&](int s) {
+    // two stage buffers: the chunks of stage s + 1 are issued before stage s is converted (a full
+    // conversion + MFMA phase of lead time, one workgroup barrier per stage)
+    constexpr int kBuf = wave_stage_lds_floats<NB>();
+    auto issue_share = [&](int s, int buf) {
+      lds_float_ptr lds = (lds_float_ptr)smem + buf * kBuf;
       static_for<8>([&](auto ec) {
         constexpr int E = decltype(ec)::value;
         const char* row = wg.template row_ptr<false, E>(R, s);
@@ -967,12 +981,14 @@ __device__ __forceinline__ void multi_body(float* smem, const KernelArgs& a, lon
       });
     };
     wg.template load_idx<false>(R, 0);
-    issue_share(0);
+    issue_share(0, 0);
     wg.template load_val<false>(R, 0);
     wg.template load_idx<false>(R, clamp(1));
     for (int s = 0; s < nst; ++s) {
-      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's chunks have landed
-      __syncthreads();                      // ... and the partner's
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's chunks of stage s (and the indices of s + 1) are here
+      __syncthreads();                      // ... and the partner's; everybody is done reading stage s - 1
+      issue_share(clamp(s + 1), (s + 1) & 1);
+      const float* lds_lane = smem + (s & 1) * kBuf + lane;
       // chunk -> registers -> planes, block by block (the raw values of one block live at a time)
       static_for<NB>([&](auto bc) {
         constexpr int B = decltype(bc)::value;
@@ -983,8 +999,6 @@ __device__ __forceinline__ void multi_body(float* smem, const KernelArgs& a, lon
         if constexpr (B == NB - 1) static_for<8>([&](auto ec) { wg.template finish_one<decltype(ec)::value>(R); });
         static_for<4>([&](auto vc) { split_pair<NB, B, decltype(vc)::value>(R, P); });
       });
-      __syncthreads();  // both waves have read the chunks: the buffer may be refilled
-      issue_share(clamp(s + 1));
       wg.template load_val<false>(R, clamp(s + 1));
       wg.template load_idx<false>(R, clamp(s + 2));
       static_for<6>([&](auto pc) {
@@ -1005,6 +1019,14 @@ __device__ __forceinline__ void multi_body(float* smem, const KernelArgs& a, lon
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // the last (unused) prefetch must land before the workgroup exits
   }
+  if constexpr (MODE == kModeCG) {
+    // a whole row (no slot): the two waves solve it where the tiles are -- 93 KB per row at f = 200 that
+    // neither go out to HBM nor come back (measured: 45 GB each way per Netflix X half-iteration)
+    if (slot < 0) {
+      cg_wave_core<NB, NW, W>(acc, smem, a, f, row, rowlen, lane);
+      return;
+    }
+  }
   float* part = a.part + (size_t)slot * NT * 256;
   static_for<TPW>([&](auto sc) {
     constexpr int t = W + NW * decltype(sc)::value;
@@ -1015,19 +1037,21 @@ __device__ __forceinline__ void multi_body(float* smem, const KernelArgs& a, lon
   });
 }
 
-template <int NB, int NW>
+template <int NB, int NW, int MODE>
 __global__ __launch_bounds__(64 * NW, NB >= 10 ? 1 : 2) void als_wave_multi_kernel(const KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63;
   const int item = blockIdx.x;
   const long long begin = a.item_begin[item];
   const int len = a.item_len[item];
-  const int slot = a.dense_slots ? item : a.item_slot[item];
+  const int slot = a.dense_slots ? item : (a.item_slot ? a.item_slot[item] : -1);
+  const int row = a.item_row[item];
+  const int rowlen = a.item_rowlen[item];
   static_assert(NW == 2, "two waves per item");
   if ((threadIdx.x >> 6) == 0)
-    multi_body<NB, NW, 0>(smem, a, begin, len, slot, lane);
+    multi_body<NB, NW, 0, MODE>(smem, a, begin, len, slot, row, rowlen, lane);
   else
-    multi_body<NB, NW, 1>(smem, a, begin, len, slot, lane);
+    multi_body<NB, NW, 1, MODE>(smem, a, begin, len, slot, row, rowlen, lane);
 }
 
 // ----------------------------------------------------------------------------------
@@ -1128,10 +1152,15 @@ template <>
 hipError_t wave_item_launch<CUMF_WAVE_NB>(const KernelArgs& a, int mode, long n_items, hipStream_t stream) {
   if (n_items <= 0) return hipSuccess;
 #if CUMF_WAVE_NB > 7
-  // dump-only kernel, two waves per item (every item must have a slot)
-  (void)mode;
-  const size_t lds = wave_stage_lds_floats<CUMF_WAVE_NB>() * sizeof(float);
-  hipLaunchKernelGGL((als_wave_multi_kernel<CUMF_WAVE_NB, 2>), dim3((unsigned)n_items), dim3(128), lds, stream, a);
+  // two waves per item; kModeCG: items without a slot (whole rows) are solved in the kernel, every
+  // other mode dumps (every item must have a slot)
+  const size_t lds = 2 * wave_stage_lds_floats<CUMF_WAVE_NB>() * sizeof(float);  // double-buffered stages
+  if (mode == kModeCG)
+    hipLaunchKernelGGL((als_wave_multi_kernel<CUMF_WAVE_NB, 2, kModeCG>), dim3((unsigned)n_items), dim3(128), lds,
+                       stream, a);
+  else
+    hipLaunchKernelGGL((als_wave_multi_kernel<CUMF_WAVE_NB, 2, kModeLU>), dim3((unsigned)n_items), dim3(128), lds,
+                       stream, a);
   return hipGetLastError();
 #else
   if (mode != kModeMaterialize && mode != kModeLU && mode != kModeCG) return hipErrorInvalidValue;
