@@ -30,6 +30,7 @@
 
 #include "als_internal.h"
 #include "als_device.h"
+#include "als_lu_wg.h"
 
 namespace cumf {
 
@@ -63,10 +64,8 @@ constexpr bool lu_on_accumulators(int nb) { return CUMF_LU_MFMA != 0 && nb >= 7;
 #define CUMF_RR_TILES 1
 #endif
 constexpr bool kRoundRobinTiles = CUMF_RR_TILES != 0;
+static_assert(kRoundRobinTiles || !CUMF_LU_MFMA, "lu_solve_mfma (als_lu_wg.h) assumes round-robin tiles");
 
-#ifndef CUMF_VARIANT_A
-#define CUMF_VARIANT_A 0  // ablation switches of tools/lu_variants.sh (timing experiments; results are wrong)
-#endif
 
 
 // ----------------------------------------------------------------------------------
@@ -638,331 +637,11 @@ __device__ __forceinline__ void lu_solve_reg(Load load, float* __restrict__ U, i
 #endif
 }
 
-// ----------------------------------------------------------------------------------
-// LU directly on the MFMA accumulators (the fused kernels' LU path).
-//
-// After the Gram pass wave W holds tiles [W*TPW, (W+1)*TPW) of the upper triangle of [A | b] in
-// the 16x16x4 C/D layout (lane (kk, c) = (l >> 4, l & 15), register r: element
-// (16 I + 4 kk + r, 16 J + c)).  The elimination keeps them there and applies FOUR pivots per
-// step as one rank-4 MFMA per tile:
-//   1. the lanes holding the panel rows p0 .. p0+3 (block row Ip, lane group kk = q) publish them
-//      raw -- updated by all earlier panels -- into the packed row store U; ONE barrier;
-//   2. every wave reads the 4x4 pivot block and eliminates it redundantly (multipliers m_kq,
-//      reciprocals 1/u_kk), then per live feature block b >= Ip reads the four raw rows at its
-//      column and forms the eliminated row of ITS lane group, ub[b] = U'[kk][16 b + c];
-//   3. A operand of tile (I, J) = -ub[I] / u_kk masked to rows below the pivot (by symmetry
-//      a_i,pk = u'_k,i), B operand = ub[J]:  acc -= L21 * U12  in one v_mfma_f32_16x16x4_f32;
-//   4. wave 0 stores the eliminated rows (final rows of U) into the row store after the NEXT
-//      barrier, when nobody reads the raw copies any more.
-// Compared with lu_solve_reg: no hand-over of the tiles through LDS, a quarter of the barriers,
-// the trailing update on the otherwise idle matrix pipe.  Unpivoted Gaussian elimination as
-// before (the content of getrfBatched(Pivot = NULL) + getrs); operation order differs from the
-// oracle's, parity is by tolerance (tests/test_gpu_parity.py).
-// ----------------------------------------------------------------------------------
-// Does wave W need the eliminated panel row at feature block b while block row Ip is being
-// eliminated?  Yes if one of its live tiles (I >= Ip) has b as its row or column block; wave 0
-// additionally finalises the panel rows (all live blocks).
-template <int NB>
-__host__ __device__ constexpr bool lu_needs_block(int W, int Ip, int b) {
-  constexpr int NT = Geo<NB>::NT, TPW = Geo<NB>::TPW;
-  if (b < Ip) return false;
-  if (W == 0) return true;
-  for (int s = 0; s < TPW; ++s) {
-    const int t = Geo<NB>::tile(W, s);
-    if (t < NT && tile_I<NB>(t) >= Ip && (tile_I<NB>(t) == b || tile_J<NB>(t) == b)) return true;
-  }
-  return false;
-}
-template <int NB>
-__host__ __device__ constexpr bool lu_wave_live(int W, int Ip) {
-  for (int b = 0; b < NB; ++b)
-    if (lu_needs_block<NB>(W, Ip, b)) return true;
-  return false;
-}
-
-// Role that holds the diagonal tile of block row Ip.
-template <int NB>
-__host__ __device__ constexpr int lu_diag_owner(int Ip) {
-  constexpr int NT = Geo<NB>::NT, TPW = Geo<NB>::TPW;
-  for (int W = 0; W < 4; ++W)
-    for (int s = 0; s < TPW; ++s) {
-      const int t = Geo<NB>::tile(W, s);
-      if (t < NT && tile_I<NB>(t) == Ip && tile_J<NB>(t) == Ip) return W;
-    }
-  return 0;
-}
-
-// Accumulator slot of the diagonal tile (Ip, Ip) in role W.
-template <int NB>
-__host__ __device__ constexpr int lu_diag_slot(int W, int Ip) {
-  constexpr int NT = Geo<NB>::NT, TPW = Geo<NB>::TPW;
-  for (int s = 0; s < TPW; ++s) {
-    const int t = Geo<NB>::tile(W, s);
-    if (t < NT && tile_I<NB>(t) == Ip && tile_J<NB>(t) == Ip) return s;
-  }
-  return 0;
-}
-
-// LDS of lu_solve_mfma (round 2): [exchange: 2 x 4 panel rows x 16 NB][window: 16 NB rows x 17]
-// [pivot reciprocals][2 x 16 multipliers][16 zeros].  f = 200: 24 KB instead of the 95 KB packed row
-// store of round 1 (one workgroup per CU); f = 100: 12.6 KB instead of 29.5 KB.
-template <int NB>
-struct LuLds {
-  static constexpr int kXRow = 16 * NB;            // one published panel row
-  static constexpr int kX = 2 * 4 * kXRow;         // double-buffered by panel parity
-  static constexpr int kPitch = 17;                // window pitch (odd: lane = row reads are conflict-free)
-  static constexpr int kT = 16 * NB * kPitch;
-};
-
 // LDS floats of the fused LU of NB feature blocks: lu_solve_mfma (NB >= 7) or the thread-grid
 // lu_solve_reg on the packed row store.
 template <int NB>
 __host__ __device__ constexpr size_t lu_fused_lds_floats(int f) {
-  return lu_on_accumulators(NB) ? (size_t)LuLds<NB>::kX + LuLds<NB>::kT + ((f + 3) & ~3) + 48 : lu_lds_floats(NB, f);
-}
-
-// Back substitution U x = y by the workgroup, straight from the accumulator tiles of the four roles
-// through the LDS window (same recurrence as back_substitute_zeroed): per 16-pivot block column kb every
-// role writes its tiles (I, kb), I <= kb, to the window (entries at and left of the diagonal as zeros),
-// barrier, wave 0 (lane i = rows i, i + 64, ...) reads the 16 entries of its rows and runs the 16 steps,
-// barrier.  2 (NB) barriers instead of a 95 KB row store.
-template <int NB, int W, int NQ>
-__device__ __forceinline__ void back_substitute_tiles_wg(const f32x4 (&acc)[Geo<NB>::TPW], float* __restrict__ T,
-                                                         const float* __restrict__ rdiag,
-                                                         const float* __restrict__ zpad, int f,
-                                                         float* __restrict__ x_global, int lane) {
-  constexpr int NT = Geo<NB>::NT, TPW = Geo<NB>::TPW, P = LuLds<NB>::kPitch;
-  const int c = lane & 15, g = lane >> 4;
-  const int top = f - 1;
-  float z[NQ], rdl[NQ];
-  const float* rowp[NQ];
-  int ib[NQ];
-  if constexpr (W == 0) {
-    static_for<NQ>([&](auto qc) {
-      constexpr int q = decltype(qc)::value;
-      const int i = lane + 64 * q;
-      const int ic = i < f ? i : f - 1;
-      ib[q] = i < f ? (i >> 4) : 1 << 20;  // rows past f never take part
-      rowp[q] = T + ic * P;
-      rdl[q] = i < f ? rdiag[ic] : 0.f;
-      z[q] = 0.f;
-    });
-  }
-  static_for<NB>([&](auto bc) {
-    constexpr int kb = NB - 1 - decltype(bc)::value;
-    constexpr int Q = kb >> 2;  // pivots of this block live in z[Q]
-    // this role's tiles of block column kb -> window
-    static_for<TPW>([&](auto sc) {
-      constexpr int s = decltype(sc)::value;
-      constexpr int t = Geo<NB>::tile(W, s);
-      if constexpr (t < NT) {
-        if constexpr (tile_J<NB>(t) == kb) {
-          constexpr int I = tile_I<NB>(t);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float v = acc[s][r];
-            if constexpr (I == kb) v = (c > 4 * g + r) ? v : 0.f;
-            T[(16 * I + 4 * g + r) * P + c] = v;
-          }
-        }
-      }
-    });
-    __syncthreads();
-    if constexpr (W == 0 && Q < NQ) {
-      if constexpr (kb == NB - 1) {  // y = column f of the last block column
-        static_for<NQ>([&](auto qc) {
-          constexpr int q = decltype(qc)::value;
-          z[q] = rowp[q][f - 16 * (NB - 1)] * rdl[q];
-        });
-      }
-      if (16 * kb <= top) {  // uniform: the last block column may hold nothing but y
-        float col[16][Q + 1];
-        static_for<Q + 1>([&](auto qc) {
-          constexpr int q = decltype(qc)::value;
-          const float* base = (ib[q] > kb) ? zpad : rowp[q];
-          static_for<16>([&](auto jc) { col[decltype(jc)::value][q] = base[decltype(jc)::value]; });
-        });
-        static_for<16>([&](auto jc) {
-          constexpr int j = 15 - decltype(jc)::value;
-          const int k = 16 * kb + j;
-          if (k <= top) {  // uniform; only the last block can be short
-            const float xk = __builtin_bit_cast(
-                float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z[Q]), k & 63));
-            static_for<Q + 1>([&](auto qc) {
-              constexpr int q = decltype(qc)::value;
-              z[q] = fmaf(-(col[j][q] * rdl[q]), xk, z[q]);
-            });
-          }
-        });
-      }
-    }
-    if constexpr (kb > 0) __syncthreads();  // the window is rewritten for the next block column
-  });
-  if constexpr (W == 0) {
-    static_for<NQ>([&](auto qc) {
-      constexpr int q = decltype(qc)::value;
-      if (lane + 64 * q < f) x_global[lane + 64 * q] = z[q];
-    });
-  }
-}
-
-template <int NB, int W>
-__device__ __forceinline__ void lu_solve_mfma(f32x4 (&acc)[Geo<NB>::TPW], float* __restrict__ lds, int f, float reg,
-                                              float* __restrict__ x_global, int tid) {
-  constexpr int NT = Geo<NB>::NT, TPW = Geo<NB>::TPW;
-  const int lane = tid & 63, c = lane & 15, kk = lane >> 4;
-  float* X = lds;                                 // published raw panel rows, [parity][r][16 NB]
-  float* Twin = lds + LuLds<NB>::kX;              // back-substitution window
-  float* rdiag = Twin + LuLds<NB>::kT;            // pivot reciprocals
-  // lambda * n_u on the diagonal (als.cu:545-557)
-  static_for<TPW>([&](auto sc) {
-    constexpr int s = decltype(sc)::value;
-    constexpr int t = Geo<NB>::tile(W, s);
-    if constexpr (t < NT) {
-      if constexpr (tile_I<NB>(t) == tile_J<NB>(t)) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (4 * kk + r == c) acc[s][r] += reg;
-      }
-    }
-  });
-  float* ctab = rdiag + ((f + 3) & ~3);  // 2 x 16 floats, 16-byte aligned
-  float* zpad = ctab + 32;               // 16 zeros (back substitution: rows outside a pivot block read these)
-  if constexpr (W == 0) {
-    if (lane < 16) zpad[lane] = 0.f;
-  }
-  static_for<NB>([&](auto ipc) {
-    constexpr int Ip = decltype(ipc)::value;
-    for (int q = 0; q < 4; ++q) {
-      const int p0 = 16 * Ip + 4 * q;
-      if (p0 >= f) break;
-#if CUMF_VARIANT_A & 32
-      if (p0 >= 0) break;
-#endif
-      // 1. publish the raw panel rows (tiles of block row Ip, lane group q)
-      static_for<TPW>([&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        constexpr int t = Geo<NB>::tile(W, s);
-        if constexpr (t < NT) {
-          if constexpr (tile_I<NB>(t) == Ip) {
-            constexpr int J = tile_J<NB>(t);
-            if (kk == q) {
-              float* xp = X + ((p0 >> 2) & 1) * 4 * LuLds<NB>::kXRow + 16 * J + c;
-#pragma unroll
-              for (int r = 0; r < 4; ++r) xp[r * LuLds<NB>::kXRow] = acc[s][r];
-            }
-          }
-        }
-      });
-      // 2a. the role that owns the diagonal tile of block row Ip has just written the 4x4 pivot
-      // block: it alone eliminates it (four dependent reciprocals, no division) and leaves, per
-      // lane group kk, the composite multipliers (c0, c1, c2) of panel row kk and -1/u_kk in a
-      // 16-float table (double-buffered by panel parity) -- the other roles just read their line.
-      // Row k of the panel after the elimination is raw_k + sum_{q<k} e_kq raw_q with e = the rows
-      // of the inverse of the panel's unit lower triangle.
-      const bool vk = p0 + kk < f;  // this lane group's pivot exists (short last panel otherwise)
-      float* tab = ctab + 16 * ((p0 >> 2) & 1);
-      float c0 = 0.f, c1 = 0.f, c2 = 0.f, nrp = 0.f;
-      constexpr int OWNER = lu_diag_owner<NB>(Ip);
-      if constexpr (W == OWNER) {
-        // the 4 x 4 pivot block sits in this role's diagonal tile: rows = registers 0..3 of lane group q,
-        // columns = lanes 4q .. 4q+3 of that group: fetch it with v_readlane, no LDS round trip
-        constexpr int SD = lu_diag_slot<NB>(OWNER, Ip);
-        const int l0 = 20 * q;  // lane of (lane group q, column 4 q)
-        auto rl = [&](float v, int l) {
-          return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-        };
-        const bool v1 = p0 + 1 < f, v2 = p0 + 2 < f, v3 = p0 + 3 < f;
-        float P00 = rl(acc[SD][0], l0), P01 = rl(acc[SD][0], l0 + 1), P02 = rl(acc[SD][0], l0 + 2),
-              P03 = rl(acc[SD][0], l0 + 3);
-        float P11 = rl(acc[SD][1], l0 + 1), P12 = rl(acc[SD][1], l0 + 2), P13 = rl(acc[SD][1], l0 + 3);
-        float P22 = rl(acc[SD][2], l0 + 2), P23 = rl(acc[SD][2], l0 + 3);
-        float P33 = rl(acc[SD][3], l0 + 3);
-        // v_rcp_f32 is accurate to 1 ulp; the four reciprocals are a dependent chain, so no Newton step
-        auto recip = [](float d) { return __builtin_amdgcn_rcpf(d); };
-        const float rp0 = recip(P00);
-        const float m10 = -P01 * rp0, m20 = -P02 * rp0, m30 = -P03 * rp0;  // -(multiplier of row k w.r.t. pivot 0)
-        P11 = fmaf(m10, P01, P11);
-        P12 = fmaf(m10, P02, P12);
-        P13 = fmaf(m10, P03, P13);
-        P22 = fmaf(m20, P02, P22);
-        P23 = fmaf(m20, P03, P23);
-        P33 = fmaf(m30, P03, P33);
-        const float rp1 = recip(v1 ? P11 : 1.0f);
-        const float m21 = -P12 * rp1, m31 = -P13 * rp1;
-        P22 = fmaf(m21, P12, P22);
-        P23 = fmaf(m21, P13, P23);
-        P33 = fmaf(m31, P13, P33);
-        const float rp2 = recip(v2 ? P22 : 1.0f);
-        const float m32 = -P23 * rp2;
-        P33 = fmaf(m32, P23, P33);
-        const float rp3 = recip(v3 ? P33 : 1.0f);
-        const float e20 = fmaf(m21, m10, m20);
-        const float e31 = fmaf(m32, m21, m31);
-        const float e30 = fmaf(m32, e20, fmaf(m31, m10, m30));
-        const float rpk = kk == 0 ? rp0 : (kk == 1 ? rp1 : (kk == 2 ? rp2 : rp3));
-        c0 = kk == 1 ? m10 : (kk == 2 ? e20 : (kk == 3 ? e30 : 0.f));
-        c1 = kk == 2 ? m21 : (kk == 3 ? e31 : 0.f);
-        c2 = kk == 3 ? m32 : 0.f;
-        nrp = vk ? -rpk : 0.f;
-        if (c < 4) tab[4 * kk + c] = c == 0 ? c0 : (c == 1 ? c1 : (c == 2 ? c2 : nrp));
-        if (c == 4 && vk) rdiag[p0 + kk] = rpk;
-      }
-      __syncthreads();
-      if constexpr (lu_wave_live<NB>(W, Ip)) {
-      const float* xb = X + ((p0 >> 2) & 1) * 4 * LuLds<NB>::kXRow;
-      const float* r0p = xb;
-      const float* r1p = xb + LuLds<NB>::kXRow;
-      const float* r2p = xb + 2 * LuLds<NB>::kXRow;
-      if constexpr (W != OWNER) {
-        const f32x4 line = *reinterpret_cast<const f32x4*>(tab + 4 * kk);
-        c0 = line[0];
-        c1 = line[1];
-        c2 = line[2];
-        nrp = line[3];
-      }
-      // 2b. eliminated panel row of this lane group at every live block: three FMAs per block
-      const float* rkp = xb + kk * LuLds<NB>::kXRow;
-      float ub[NB];
-      static_for<NB>([&](auto bc) {
-        constexpr int b = decltype(bc)::value;
-        if constexpr (lu_needs_block<NB>(W, Ip, b)) {
-          const float own = rkp[16 * b + c];
-          const float a0 = r0p[16 * b + c], a1 = r1p[16 * b + c], a2 = r2p[16 * b + c];
-          // lanes of a pivot past f (short last panel) keep a finite dummy: their A operand is 0
-#if CUMF_VARIANT_A & 64
-          ub[b] = own + c0 + c1 + c2;
-          (void)a0; (void)a1; (void)a2;
-#else
-          ub[b] = fmaf(c2, a2, fmaf(c1, a1, fmaf(c0, a0, own)));
-#endif
-        }
-      });
-      // 3. rank-4 update of the live tiles
-      static_for<TPW>([&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        constexpr int t = Geo<NB>::tile(W, s);
-        if constexpr (t < NT) {
-          constexpr int I = tile_I<NB>(t), J = tile_J<NB>(t);
-          if constexpr (I >= Ip) {
-            float la = ub[I] * nrp;
-            if constexpr (I == Ip) la = (c > 4 * q + kk) ? la : 0.f;  // rows at or above the pivot stay
-#if CUMF_VARIANT_A & 2
-            acc[s][0] += la * ub[J];
-#else
-            acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(la, ub[J], acc[s], 0, 0, 0);
-#endif
-          }
-        }
-      });
-      }  // lu_wave_live
-    }
-  });
-  // the eliminated rows stay in the accumulators (the masked update leaves rows at and above a pivot alone)
-  __syncthreads();  // rdiag is complete
-#if !(CUMF_VARIANT_A & 8)
-  back_substitute_tiles_wg<NB, W, (16 * NB + 63) / 64>(acc, Twin, rdiag, zpad, f, x_global, lane);
-#endif
+  return lu_on_accumulators(NB) ? lu_wg_lds_floats<NB>(f) : lu_lds_floats(NB, f);
 }
 
 // Loaders of lu_solve_reg.  TileLoad: the accumulator tiles parked in LDS by tiles_to_tiled.
@@ -1597,8 +1276,11 @@ static hipError_t launch_batched_nb(const KernelArgs& a0, int mode, const PlanLi
     e = launch_reduce_only<NB>(a0, mode, L.n_mrows, stream);
     if (e != hipSuccess) return e;
   }
-  // 2. whole rows.  CG: solved by the two waves that formed the Gram, in one launch
-  if (mode == kModeCG) {
+  // 2. whole rows.  CG, and LU up to NB = 9: solved by the two waves that formed the Gram, in one launch.
+  // Larger LUs go on through the tile buffer: two waves on a 200 x 200 elimination (one wave per SIMD, a
+  // barrier per panel) lose more than the round trip costs (Netflix f = 200: 112 vs 106 ms, f = 160: 85
+  // vs 78; f = 128: 39.0 vs 41.6 the other way).
+  if (mode == kModeCG || (mode == kModeLU && NB <= kMaxFusedLuWaveNB)) {
     if (L.n_witems <= 0) return hipSuccess;
     KernelArgs a = a0;
     a.item_row = L.w_row;
@@ -1607,9 +1289,9 @@ static hipError_t launch_batched_nb(const KernelArgs& a0, int mode, const PlanLi
     a.item_rowlen = L.w_rowlen;
     a.item_slot = nullptr;  // no slots: nothing is dumped
     a.dense_slots = 0;
-    return wave_item_launch<NB>(a, kModeCG, L.n_witems, stream);
+    return wave_item_launch<NB>(a, mode, L.n_witems, stream);
   }
-  // LU / materialise: in batches of part2_rows dense slots
+  // large LU / materialise (cumf_get_hermitian): in batches of part2_rows dense slots
   for (long w0 = 0; w0 < L.n_witems; w0 += L.part2_rows) {
     const long cnt = L.n_witems - w0 < L.part2_rows ? L.n_witems - w0 : L.part2_rows;
     KernelArgs a = a0;

@@ -324,7 +324,7 @@ extern "C" int cumf_als_update_fused(const cumf_plan_t* p, const int* colidx, co
   (void)long_rows;
   const bool batched = wave_batched_path(f, mode);
   if (batched) {
-    const int rc = plan_lists(p, &lists, mode != kModeCG);
+    const int rc = plan_lists(p, &lists, mode == kModeLU && p->nb > kMaxFusedLuWaveNB);  // else solved in the Gram kernel
     if (rc) return rc;
   }
   CUMF_HIP_CHECK(launch_half_iteration(a, mode, p->n_items, p->n_mrows, static_cast<hipStream_t>(stream),

@@ -38,6 +38,7 @@
 #include <type_traits>
 
 #include "als_device.h"
+#include "als_lu_wg.h"
 #include "als_internal.h"
 
 namespace cumf {
@@ -1019,13 +1020,16 @@ __device__ __forceinline__ void multi_body(float* smem, const KernelArgs& a, lon
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // the last (unused) prefetch must land before the workgroup exits
   }
-  if constexpr (MODE == kModeCG) {
-    // a whole row (no slot): the two waves solve it where the tiles are -- 93 KB per row at f = 200 that
-    // neither go out to HBM nor come back (measured: 45 GB each way per Netflix X half-iteration)
-    if (slot < 0) {
+  // a whole row (no slot): the two waves solve it where the tiles are -- 93 KB per row at f = 200 that
+  // neither go out to HBM nor come back (measured: 45 GB each way per Netflix X half-iteration)
+  if (slot < 0) {
+    if constexpr (MODE == kModeCG) {
       cg_wave_core<NB, NW, W>(acc, smem, a, f, row, rowlen, lane);
-      return;
+    } else {
+      __syncthreads();  // the partner is done with the stage buffers: the LU's exchange buffers alias them
+      lu_solve_mfma<NB, W, NW>(acc, smem, f, (float)rowlen * a.lambda, a.update + (size_t)row * f, lane);
     }
+    return;
   }
   float* part = a.part + (size_t)slot * NT * 256;
   static_for<TPW>([&](auto sc) {
@@ -1152,9 +1156,10 @@ template <>
 hipError_t wave_item_launch<CUMF_WAVE_NB>(const KernelArgs& a, int mode, long n_items, hipStream_t stream) {
   if (n_items <= 0) return hipSuccess;
 #if CUMF_WAVE_NB > 7
-  // two waves per item; kModeCG: items without a slot (whole rows) are solved in the kernel, every
-  // other mode dumps (every item must have a slot)
-  const size_t lds = 2 * wave_stage_lds_floats<CUMF_WAVE_NB>() * sizeof(float);  // double-buffered stages
+  // two waves per item; items without a slot (whole rows) are solved in the kernel (CG, or the LU of
+  // als_lu_wg.h with two wave roles), items with one dump their tiles
+  size_t lds = 2 * wave_stage_lds_floats<CUMF_WAVE_NB>() * sizeof(float);  // double-buffered stages
+  if (lu_wg_lds_floats<CUMF_WAVE_NB>(a.f) * sizeof(float) > lds) lds = lu_wg_lds_floats<CUMF_WAVE_NB>(a.f) * sizeof(float);
   if (mode == kModeCG)
     hipLaunchKernelGGL((als_wave_multi_kernel<CUMF_WAVE_NB, 2, kModeCG>), dim3((unsigned)n_items), dim3(128), lds,
                        stream, a);
