@@ -44,5 +44,8 @@ if what in ("all", "quick"):
 if what in ("all", "f200"):
     run("netflix", 128, "lu")
     run("netflix", 128, "cg")
-    run("netflix", 200, "cg", fused=False, theta_batch=10)
+    run("netflix", 160, "lu", iters=1)
+    run("netflix", 160, "cg", iters=1)
+    run("netflix", 200, "cg", iters=1)
     run("netflix", 200, "lu", iters=1)
+    run("netflix", 200, "cg", fused=False, theta_batch=10, iters=1)
