@@ -154,6 +154,7 @@ def update_fused(plan: Plan, colidx, val, gather, update, lambda_: float, solver
 
     lib = _libmod.load()
     _libmod.check(lib.cumf_check_gather_table(gather.shape[0], plan.f, _solver_id(solver), 0), "cumf_check_gather_table")
+    _libmod.check(lib.cumf_plan_set_gather_rows(plan._h, int(gather.shape[0])), "cumf_plan_set_gather_rows")
     _libmod.check(lib.cumf_als_update_fused(plan._h, _dp(colidx, torch.int32), _dp(val, torch.float32),
                                             _dp(gather, torch.float32), _dp(update, torch.float32), plan.f,
                                             float(lambda_), _solver_id(solver), int(cg_iters), _stream()),
@@ -258,18 +259,29 @@ def sse(val, row, col, thetaT, XT, count: int | None = None, surpass_nan: bool =
     return out
 
 
-GRAM_AUTO, GRAM_EXACT = 0, 1
+GRAM_AUTO, GRAM_EXACT, GRAM_FAST = 0, 1, 2
 
 
 def set_gram_mode(mode) -> None:
     """Arithmetic of the Gram pass (cumf_set_gram_mode): "auto"/"split" = fp32 via exact bf16x3
-    splits on the bf16 matrix pipe where available, "exact" = fp32 MFMA (fmaf-chain bits)."""
-    m = {"auto": GRAM_AUTO, "split": GRAM_AUTO, "exact": GRAM_EXACT}.get(mode, mode)
+    splits on the bf16 matrix pipe where available, "exact" = fp32 MFMA (fmaf-chain bits), "fast"
+    (opt-in) = pre-split f16 pairs, three products, 22 significand bits, |values| < 15.99."""
+    m = {"auto": GRAM_AUTO, "split": GRAM_AUTO, "exact": GRAM_EXACT, "fast": GRAM_FAST}.get(mode, mode)
     _libmod.check(_libmod.load().cumf_set_gram_mode(int(m)), "cumf_set_gram_mode")
 
 
 def get_gram_mode() -> str:
-    return "exact" if _libmod.load().cumf_get_gram_mode() == GRAM_EXACT else "auto"
+    return {GRAM_EXACT: "exact", GRAM_FAST: "fast"}.get(_libmod.load().cumf_get_gram_mode(), "auto")
+
+
+def gram_fast_status() -> int:
+    """Range report of gram mode "fast" since the last call (waits for the device; cumf_gram_fast_status):
+    bit 0 = a factor, bit 1 = a rating beyond the f16 range; 0 = clean."""
+    import ctypes as C
+
+    flags = C.c_int(0)
+    _libmod.check(_libmod.load().cumf_gram_fast_status(C.byref(flags)), "cumf_gram_fast_status")
+    return int(flags.value)
 
 
 def set_kernel_timing(enable: bool) -> None:

@@ -55,13 +55,14 @@ struct Side {
   std::vector<long> offset, size;
 };
 
-void make_side(Side& s, int f) {
+void make_side(Side& s, int f, long gather_rows) {
   for (int b = 0; b < s.nbatch; ++b) {
     // als.cu:768-777
     const long bs = (b != s.nbatch - 1) ? s.rows / s.nbatch : s.rows - (long)b * (s.rows / s.nbatch);
     const long off = (long)b * (s.rows / s.nbatch);
     cumf_plan_t* p = nullptr;
     DRV_CHECK(cumf_plan_create(&p, s.rowptr_host, 0, s.rows, off, off + bs, f, 0));
+    DRV_CHECK(cumf_plan_set_gather_rows(p, gather_rows));  // gram mode "fast" pre-splits the gather table
     s.plans.push_back(p);
     s.offset.push_back(off);
     s.size.push_back(bs);
@@ -124,8 +125,8 @@ extern "C" float cumf_doALS_ex(const int* csrRowIndexHostPtr, const int* csrColI
 
   Side sx{csrRowIndexHostPtr, csrColIndex, csrVal, m, X_BATCH, {}, {}, {}};
   Side st{cscColIndexHostPtr, cscRowIndex, cscVal, n, THETA_BATCH, {}, {}, {}};
-  make_side(sx, f);
-  make_side(st, f);
+  make_side(sx, f, n);  // X rows gather from thetaT (n rows)
+  make_side(st, f, m);  // Theta rows gather from XT (m rows)
 
   // unfused path: Gram batch `tt` (als.cu:782,897) + RHS (ythetaT / yTXT, als.cu:746,864)
   float *tt = nullptr, *rhs = nullptr;
@@ -167,6 +168,15 @@ extern "C" float cumf_doALS_ex(const int* csrRowIndexHostPtr, const int* csrColI
   for (int iter = 0; iter < ITERS; iter++) {
     half_iteration(sx, thetaT, XT);  // update X      (als.cu:727-855)
     half_iteration(st, XT, thetaT);  // update Theta  (als.cu:857-964)
+    if (cumf_get_gram_mode() == CUMF_GRAM_FAST) {
+      int flags = 0;
+      DRV_CHECK(cumf_gram_fast_status(&flags));
+      if (flags) {
+        fprintf(stderr, "doALS: gram mode \"fast\": %s beyond the f16 range (|value| >= 15.99) in iteration %d; "
+                        "use CUMF_ALS_GRAM=split\n", (flags & 1) ? "a factor" : "a rating", iter);
+        exit(1);
+      }
+    }
 
     // RMSE (als.cu:966-1020).  The test grid of the reference is (nnz_test-1)/256 blocks
     // -- one short of covering the set (als.cu:1006) -- yet divides by nnz_test.

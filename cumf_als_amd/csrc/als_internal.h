@@ -75,6 +75,10 @@ struct KernelArgs {
   float lambda;
   int cg_iters;
   int dbg;  // ablation switches for profiling (CUMF_ALS_DBG); 0 in production
+  // gram mode "fast": `gather` points at the pre-split (h, l) f16 words of the factor table
+  // (presplit_f16x2_kernel) and range violations are OR-ed into *fast_flag (bit 0: table, bit 1: ratings)
+  int fast_words;
+  int* fast_flag;
 };
 
 // Work lists of a plan as the launchers see them (device arrays of als_plan.cpp).
@@ -99,7 +103,10 @@ hipError_t launch_solve_batched(const float* A, const float* b, float* x, long b
 //               product, fp32 accumulation (als_wave.hip; fp32-class error, not bit-identical to a
 //               fmaf chain); used where the wave-per-item kernels exist (LU and materialise, f <= 111),
 //   kGramExact: v_mfma_f32_16x16x4_f32, bit-identical to the reference thread's fmaf chain.
-enum { kGramAuto = 0, kGramExact = 1 };
+//   kGramFast (opt-in): the factor table pre-split into (h, l) f16 pairs of 4096 x, three f16 MFMA
+//               products per fp32 product (22 significand bits); fused LU / CG passes of the wave
+//               kernels only, everything else as kGramAuto; values must stay below 15.99 in magnitude.
+enum { kGramAuto = 0, kGramExact = 1, kGramFast = 2 };
 void set_gram_mode(int mode);
 int gram_mode();
 bool wave_path_available(int f, int mode);
@@ -107,6 +114,7 @@ bool wave_path_available(int f, int mode);
 bool wave_batched_path(int f, int mode);
 // unpack = 0: full (batch x f x f) -> packed (batch x f(f+1)/2); unpack = 1: `full` is the packed input,
 // `packed` receives the mirrored full matrices
+hipError_t launch_presplit(const float* src, unsigned* dst, size_t n, int* flag, hipStream_t stream);
 hipError_t launch_pack_upper(const float* full, float* packed, long batch, int f, int unpack, hipStream_t stream);
 void set_kernel_timing(bool on);
 hipError_t last_kernel_ms(float* item_ms, float* reduce_ms);

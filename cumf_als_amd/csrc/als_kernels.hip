@@ -1077,6 +1077,43 @@ __global__ __launch_bounds__(kThreads) void unpack_upper_kernel(const float* __r
     A[e] = P[a * f - a * (a - 1) / 2 + (b - a)];
   }
 }
+// Gram mode "fast": factor table -> (h, l) f16 words of 4096 x (round to nearest even; als_wave.hip
+// kArithFast).  Values whose scaled magnitude leaves the f16 range (|x| >= 15.99) or that are not finite
+// are reported through *flag (bit 0).
+__global__ __launch_bounds__(256) void presplit_f16x2_kernel(const float* __restrict__ src,
+                                                            unsigned* __restrict__ dst, size_t n4, size_t n,
+                                                            int* __restrict__ flag) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  auto word = [](float x, bool& bad) {
+    const float s = x * 4096.0f;
+    bad = bad || !(__builtin_fabsf(s) < 65504.0f);
+    const _Float16 h = (_Float16)s;
+    const _Float16 l = (_Float16)(s - (float)h);
+    h2 w = {h, l};
+    return __builtin_bit_cast(unsigned, w);
+  };
+  bool bad = false;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(src)[i];
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    u4 o = {word(v[0], bad), word(v[1], bad), word(v[2], bad), word(v[3], bad)};
+    reinterpret_cast<u4*>(dst)[i] = o;
+  }
+  for (size_t i = 4 * n4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = word(src[i], bad);
+  if (bad) atomicOr(flag, 1);
+}
+hipError_t launch_presplit(const float* src, unsigned* dst, size_t n, int* flag, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  const bool aligned = (reinterpret_cast<uintptr_t>(src) % 16 == 0) && (reinterpret_cast<uintptr_t>(dst) % 16 == 0);
+  const size_t n4 = aligned ? n / 4 : 0;
+  size_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(presplit_f16x2_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src, dst, n4, n, flag);
+  return hipGetLastError();
+}
+
 hipError_t launch_pack_upper(const float* full, float* packed, long batch, int f, int unpack, hipStream_t stream) {
   if (batch <= 0) return hipSuccess;
   if (unpack)
@@ -1447,11 +1484,11 @@ CUMF_STUB_SLICE(13)
 #define CUMF_NB_CASE(N, call) case N: return call;
 
 static int g_gram_mode = -1;
-void set_gram_mode(int mode) { g_gram_mode = mode == kGramExact ? kGramExact : kGramAuto; }
+void set_gram_mode(int mode) { g_gram_mode = (mode == kGramExact || mode == kGramFast) ? mode : kGramAuto; }
 int gram_mode() {
   if (g_gram_mode < 0) {
-    const char* e = getenv("CUMF_ALS_GRAM");  // exact | split (default)
-    g_gram_mode = (e && (e[0] == 'e' || e[0] == 'E')) ? kGramExact : kGramAuto;
+    const char* e = getenv("CUMF_ALS_GRAM");  // exact | fast | split (default)
+    g_gram_mode = (e && (e[0] == 'e' || e[0] == 'E')) ? kGramExact : (e && (e[0] == 'f' || e[0] == 'F')) ? kGramFast : kGramAuto;
   }
   return g_gram_mode;
 }

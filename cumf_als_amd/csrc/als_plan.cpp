@@ -47,6 +47,10 @@ struct cumf_plan {
   long long* d_w_begin = nullptr;
   float* d_part2 = nullptr;
   long part2_rows = 0;
+  // gram mode "fast": rows of the gather table (cumf_plan_set_gather_rows) and its pre-split copy
+  long gather_rows = 0;
+  unsigned* d_words = nullptr;
+  size_t words_cap = 0;
 };
 
 namespace {
@@ -230,10 +234,17 @@ extern "C" int cumf_plan_destroy(cumf_plan_t* p) {
   void* ptrs[] = {p->d_item_row,  p->d_item_begin,  p->d_item_len,    p->d_item_slot,   p->d_item_rowlen,
                   p->d_mrow_row,  p->d_mrow_slot0,  p->d_mrow_nslots, p->d_mrow_rowlen, p->d_part,
                   p->d_c_row,     p->d_c_begin,     p->d_c_len,       p->d_c_slot,      p->d_c_rowlen,
-                  p->d_w_row,     p->d_w_begin,     p->d_w_len,       p->d_w_rowlen,    p->d_part2};
+                  p->d_w_row,     p->d_w_begin,     p->d_w_len,       p->d_w_rowlen,    p->d_part2,
+                  p->d_words};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   delete p;
+  return 0;
+}
+
+extern "C" int cumf_plan_set_gather_rows(cumf_plan_t* p, long gather_rows) {
+  if (!p || gather_rows < 0) return (int)hipErrorInvalidValue;
+  p->gather_rows = gather_rows;
   return 0;
 }
 
@@ -289,7 +300,47 @@ KernelArgs base_args(const cumf_plan_t* p, const int* colidx, const float* val, 
   return a;
 }
 
+// Gram mode "fast": the factor table as (h, l) f16 words, rebuilt per call (the factors change every
+// half-iteration: 2 x 192 MB of traffic for the Netflix X table, ~0.1 ms), kept with the plan.
+int* g_fast_flag = nullptr;
+int fast_words(cumf_plan_t* p, const float* gather, int f, hipStream_t stream, KernelArgs* a) {
+  if (p->gather_rows <= 0) {
+    fprintf(stderr, "cumf_als_update_fused: gram mode \"fast\" needs the row count of the gather table "
+                    "(cumf_plan_set_gather_rows)\n");
+    return (int)hipErrorInvalidValue;
+  }
+  const size_t n = (size_t)p->gather_rows * f;
+  if (p->words_cap < n) {
+    if (p->d_words) (void)hipFree(p->d_words);
+    p->d_words = nullptr;
+    p->words_cap = 0;
+    CUMF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p->d_words), n * sizeof(unsigned)));
+    p->words_cap = n;
+  }
+  if (!g_fast_flag) {
+    CUMF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g_fast_flag), sizeof(int)));
+    CUMF_HIP_CHECK(hipMemset(g_fast_flag, 0, sizeof(int)));
+  }
+  CUMF_HIP_CHECK(launch_presplit(gather, p->d_words, n, g_fast_flag, stream));
+  a->gather = reinterpret_cast<const float*>(p->d_words);
+  a->fast_words = 1;
+  a->fast_flag = g_fast_flag;
+  return 0;
+}
+
 }  // namespace
+
+// Range report of gram mode "fast" since the last call (waits for the device): bit 0 = a factor beyond
+// the f16 range of the pre-split table, bit 1 = a rating beyond it (the affected rows are not finite).
+extern "C" int cumf_gram_fast_status(int* flags) {
+  if (!flags) return (int)hipErrorInvalidValue;
+  *flags = 0;
+  if (!g_fast_flag) return 0;
+  CUMF_HIP_CHECK(hipDeviceSynchronize());
+  CUMF_HIP_CHECK(hipMemcpy(flags, g_fast_flag, sizeof(int), hipMemcpyDeviceToHost));
+  CUMF_HIP_CHECK(hipMemset(g_fast_flag, 0, sizeof(int)));
+  return 0;
+}
 
 // Can one fused call (RHS + Gram + solve) handle (f, solver)?  The workgroup kernels: CG f <= 128, LU
 // f <= 200; the wave kernels and the tile-batched path (gram mode auto): both solvers up to f = 207.
@@ -325,6 +376,10 @@ extern "C" int cumf_als_update_fused(const cumf_plan_t* p, const int* colidx, co
   const bool batched = wave_batched_path(f, mode);
   if (batched) {
     const int rc = plan_lists(p, &lists, mode == kModeLU && p->nb > kMaxFusedLuWaveNB);  // else solved in the Gram kernel
+    if (rc) return rc;
+  }
+  if (gram_mode() == kGramFast && (batched || wave_path_available(f, mode))) {
+    const int rc = fast_words(const_cast<cumf_plan_t*>(p), gather, f, static_cast<hipStream_t>(stream), &a);
     if (rc) return rc;
   }
   CUMF_HIP_CHECK(launch_half_iteration(a, mode, p->n_items, p->n_mrows, static_cast<hipStream_t>(stream),
@@ -437,7 +492,7 @@ extern "C" int cumf_check_gather_table(long gather_rows, int f, int solver, int 
 }
 
 extern "C" int cumf_set_gram_mode(int mode) {
-  if (mode != CUMF_GRAM_AUTO && mode != CUMF_GRAM_EXACT) return (int)hipErrorInvalidValue;
+  if (mode != CUMF_GRAM_AUTO && mode != CUMF_GRAM_EXACT && mode != CUMF_GRAM_FAST) return (int)hipErrorInvalidValue;
   set_gram_mode(mode);
   return 0;
 }

@@ -46,6 +46,8 @@ namespace cumf {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef __attribute__((address_space(3))) float* lds_float_ptr;  // LDS pointer kept in its own address space (M0 operand)
@@ -91,6 +93,27 @@ __device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
                                                  0);
 }
 
+__device__ __forceinline__ f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// Arithmetic of the Gram pass.  kArithSplit3: exact bf16x3 split, six products (24 significand bits).
+// kArithFast: the gather table arrives PRE-SPLIT (presplit_f16x2_kernel, als_kernels.hip): one 32-bit word
+// per value = (h, l) f16 pair of 4096 x, x ~ (h + l) / 4096 to 2^-22; three f16 products hh + hl + lh
+// (the dropped ll is < 2^-22 of the product), fp32 accumulation, accumulators scaled back by 2^-24.
+enum { kArithSplit3 = 0, kArithFast = 1 };
+constexpr float kFastScale = 4096.0f;             // values must stay below 65504 / 4096 = 15.99 in magnitude
+constexpr float kFastUnscale = 1.0f / (4096.0f * 4096.0f);
+
+// (h, l) word of one fp32 value, as presplit_f16x2_kernel makes them (round to nearest even)
+__device__ __forceinline__ unsigned fast_word(float x) {
+  const float s = x * kFastScale;
+  const _Float16 h = (_Float16)s;
+  const _Float16 l = (_Float16)(s - (float)h);
+  f16x2 w = {h, l};
+  return __builtin_bit_cast(unsigned, w);
+}
+
 // ----------------------------------------------------------------------------------
 // One 32-rating stage in flight: the raw gathered values in the operand layout and its
 // column indices.  Planes: the three bf16 terms of a converted stage.
@@ -101,9 +124,13 @@ struct WaveStage {
   float rv[8];       // rating values (lanes of slot f; zeros elsewhere)
   int idx[8];        // column indices of a stage whose gathers are still to be issued
 };
-template <int NB>
+template <int NB, int ARITH = kArithSplit3>
 struct Planes {
   u32x4 h[NB], m[NB], l[NB];
+};
+template <int NB>
+struct Planes<NB, kArithFast> {
+  u32x4 h[NB], l[NB];
 };
 
 // Loop-invariant per-lane state of the gather.  FULL forms assume every rating of the stage
@@ -238,9 +265,14 @@ struct WaveGather {
   }
 
   // after the loads have landed: the rating / the zero padding into rating E of the last block
-  template <int E>
+  template <int E, int ARITH = kArithSplit3>
   __device__ __forceinline__ void finish_one(WaveStage<NB>& st) const {
-    st.raw[NB - 1][E] = is_feat ? st.raw[NB - 1][E] : st.rv[E];
+    if constexpr (ARITH == kArithFast) {  // the table words are pre-split, the rating is split here
+      float w = __builtin_bit_cast(float, fast_word(st.rv[E]));
+      asm volatile("" : "+v"(w));  // computed by every lane, then ONE select (a conditional conversion compiles to exec-mask branches)
+      st.raw[NB - 1][E] = is_feat ? st.raw[NB - 1][E] : w;
+    } else
+      st.raw[NB - 1][E] = is_feat ? st.raw[NB - 1][E] : st.rv[E];
   }
 };
 
@@ -278,10 +310,30 @@ __device__ __forceinline__ void split_pair(const WaveStage<NB>& st, Planes<NB>& 
   SplitState x;
   static_for<6>([&](auto sc) { split_micro<NB, B, V, decltype(sc)::value>(st, P, x); });
 }
+// kArithFast: the stage registers hold (h, l) words; the operand words pair two ratings: two v_perm_b32
+template <int NB, int B, int V>
+__device__ __forceinline__ void split_pair(const WaveStage<NB>& st, Planes<NB, kArithFast>& P) {
+  const unsigned wa = __builtin_bit_cast(unsigned, st.raw[B][2 * V]);
+  const unsigned wb = __builtin_bit_cast(unsigned, st.raw[B][2 * V + 1]);
+  P.h[B][V] = __builtin_amdgcn_perm(wb, wa, 0x05040100u);  // (h of rating 2 V, h of rating 2 V + 1)
+  P.l[B][V] = __builtin_amdgcn_perm(wb, wa, 0x07060302u);
+}
 
 // n-th MFMA of a stage, n in [0, 6 NT): product n / NT of tile n % NT -- consecutive MFMAs hit
 // different accumulators.  tile(I, J) += sum over the 32 ratings of theta[16 I + i] theta[16 J + j]
 // as lh + hl + mm + mh + hm + hh (small terms first).
+template <int ARITH>
+constexpr int gram_products() { return ARITH == kArithFast ? 3 : 6; }
+// kArithFast: lh + hl + hh
+template <int NB, int N>
+__device__ __forceinline__ void gram_mfma(const Planes<NB, kArithFast>& P, f32x4 (&acc)[NB * (NB + 1) / 2]) {
+  constexpr int NT = NB * (NB + 1) / 2;
+  constexpr int prod = N / NT, t = N % NT;
+  constexpr int I = tile_I<NB>(t), J = tile_J<NB>(t);
+  if constexpr (prod == 0) acc[t] = mfma_f16(P.l[I], P.h[J], acc[t]);
+  if constexpr (prod == 1) acc[t] = mfma_f16(P.h[I], P.l[J], acc[t]);
+  if constexpr (prod == 2) acc[t] = mfma_f16(P.h[I], P.h[J], acc[t]);
+}
 template <int NB, int N>
 __device__ __forceinline__ void gram_mfma(const Planes<NB>& P, f32x4 (&acc)[NB * (NB + 1) / 2]) {
   constexpr int NT = NB * (NB + 1) / 2;
@@ -305,26 +357,30 @@ __device__ __forceinline__ void gram_mfma(const Planes<NB>& P, f32x4 (&acc)[NB *
 //   wait for the chunks of stage s -> registers -> issue the chunks of stage s + 1 -> split ->
 //   6 NT MFMAs.
 // ----------------------------------------------------------------------------------
-template <int NB, int PROD>
-__device__ __forceinline__ void gram_product(const Planes<NB>& P, f32x4 (&acc)[NB * (NB + 1) / 2]) {
+template <int NB, int PROD, int ARITH>
+__device__ __forceinline__ void gram_product(const Planes<NB, ARITH>& P, f32x4 (&acc)[NB * (NB + 1) / 2]) {
   constexpr int NT = NB * (NB + 1) / 2;
   static_for<NT>([&](auto tc) { gram_mfma<NB, PROD * NT + decltype(tc)::value>(P, acc); });
 }
 
-template <int NB, bool FULL>
-__device__ __forceinline__ void stage_step(const WaveGather<NB>& wg, Planes<NB>& P, WaveStage<NB>& R, lds_float_ptr lds,
+enum { kStepPartial = 0, kStepFull = 1, kStepLast = 2 };  // prefetch of the step: clamped / select-free / none (last stage of the item)
+template <int NB, int KIND, int ARITH>
+__device__ __forceinline__ void stage_step(const WaveGather<NB>& wg, Planes<NB, ARITH>& P, WaveStage<NB>& R, lds_float_ptr lds,
                                            const float* lds_lane, f32x4 (&acc)[NB * (NB + 1) / 2], int s_next,
                                            int s_idx) {
   // in flight: chunks + ratings of the stage that is multiplied now, indices of stage s_next
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the LDS-DMA chunks have landed
   wg.dma_read(R, lds_lane);
-  static_for<8>([&](auto ec) { wg.template finish_one<decltype(ec)::value>(R); });  // consumes R.rv
+  static_for<8>([&](auto ec) { wg.template finish_one<decltype(ec)::value, ARITH>(R); });  // consumes R.rv
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the chunks are in registers, the buffer is free
-  if (!(wg.dbg & 16)) wg.template dma_issue<FULL>(R, lds, s_next);                     // consumes R.idx
-  wg.template load_val<FULL>(R, s_next);
-  wg.template load_idx<FULL>(R, s_idx);
+  if constexpr (KIND != kStepLast) {
+    constexpr bool FULL = KIND == kStepFull;
+    if (!(wg.dbg & 16)) wg.template dma_issue<FULL>(R, lds, s_next);  // consumes R.idx
+    wg.template load_val<FULL>(R, s_next);
+    wg.template load_idx<FULL>(R, s_idx);
+  }
   static_for<4 * NB>([&](auto uc) { split_pair<NB, decltype(uc)::value / 4, decltype(uc)::value % 4>(R, P); });
-  static_for<6>([&](auto pc) { gram_product<NB, decltype(pc)::value>(P, acc); });
+  static_for<gram_products<ARITH>()>([&](auto pc) { gram_product<NB, decltype(pc)::value>(P, acc); });
 }
 
 // ----------------------------------------------------------------------------------
@@ -855,7 +911,26 @@ __global__ __launch_bounds__(64 * NW, 2) void als_wave_cg_kernel(const KernelArg
 #else
 #define CUMF_WAVE_MIN_WAVES 2
 #endif
-template <int NB, int MODE, int FC>
+// kArithFast epilogue of the Gram pass: the accumulators carry 4096^2 x the Gram; a rating beyond the
+// f16 range (|r| >= 15.99; the table is checked by presplit_f16x2_kernel) shows as a non-finite
+// right-hand side (column f lives in the tiles of the last block column) and is reported through
+// a.fast_flag (cumf_gram_fast_status).  NW, W: tile t belongs to wave t % NW, slot t / NW.
+template <int NB, int NW, int W>
+__device__ __forceinline__ void fast_unscale(f32x4 (&acc)[(NB * (NB + 1) / 2 + NW - 1) / NW], int* flag) {
+  constexpr int NT = NB * (NB + 1) / 2, TPW = (NT + NW - 1) / NW;
+  float probe = 0.f;
+  static_for<TPW>([&](auto sc) {
+    constexpr int sl = decltype(sc)::value, t = W + NW * sl;
+    if constexpr (t < NT) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[sl][r] *= kFastUnscale;
+      if constexpr (tile_J<NB>(t) == NB - 1) probe += (acc[sl][0] + acc[sl][1]) + (acc[sl][2] + acc[sl][3]);
+    }
+  });
+  if (!(__builtin_fabsf(probe) <= 3.0e38f)) atomicOr(flag, 2);
+}
+
+template <int NB, int MODE, int FC, int ARITH = kArithSplit3>
 __global__ __launch_bounds__(64, CUMF_WAVE_MIN_WAVES) void als_wave_kernel(const KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = NB * (NB + 1) / 2;
@@ -888,7 +963,7 @@ __global__ __launch_bounds__(64, CUMF_WAVE_MIN_WAVES) void als_wave_kernel(const
     WaveGather<NB> wg;
     wg.init(a, f, begin, len, lane);
     WaveStage<NB> R;
-    Planes<NB> P;
+    Planes<NB, ARITH> P;
     lds_float_ptr lds = (lds_float_ptr)smem;  // staging chunks of this wave (the LU window aliases them later)
     const float* lds_lane = smem + lane;
     auto clamp = [&](int s) { return s < nst ? s : nst - 1; };
@@ -898,12 +973,13 @@ __global__ __launch_bounds__(64, CUMF_WAVE_MIN_WAVES) void als_wave_kernel(const
     wg.template load_val<false>(R, 0);
     wg.template load_idx<false>(R, clamp(1));
     int s = 0;
-    // stages s + 1, s + 2 full: select-free steps.  Past the end the loads are re-issued on the
-    // last stage (in bounds, never used): the step stays branch-free.
-    for (; s + 2 < nfull; ++s) stage_step<NB, true>(wg, P, R, lds, lds_lane, acc, s + 1, s + 2);
-    for (; s < nst; ++s) stage_step<NB, false>(wg, P, R, lds, lds_lane, acc, clamp(s + 1), clamp(s + 2));
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // the last (unused) prefetch must land before the window is reused
+    // stages s + 1, s + 2 full: select-free steps; then the clamped form; the last stage of the item
+    // prefetches nothing (three step bodies, each branch-free)
+    for (; s + 2 < nfull; ++s) stage_step<NB, kStepFull, ARITH>(wg, P, R, lds, lds_lane, acc, s + 1, s + 2);
+    for (; s + 1 < nst; ++s) stage_step<NB, kStepPartial, ARITH>(wg, P, R, lds, lds_lane, acc, s + 1, clamp(s + 2));
+    stage_step<NB, kStepLast, ARITH>(wg, P, R, lds, lds_lane, acc, 0, 0);  // the last stage prefetches nothing
   }
+  if constexpr (ARITH == kArithFast) fast_unscale<NB, 1, 0>(acc, a.fast_flag);
 
   if (slot >= 0) {
     wave_tiles_to_partial<NB>(acc, a.part + (size_t)slot * NT * 256, lane);
@@ -942,7 +1018,7 @@ __global__ __launch_bounds__(64, CUMF_WAVE_MIN_WAVES) void als_wave_kernel(const
 // als_reduce_kernel finishes the rows (LU, CG for f <= 128, or the materialised f x f Gram for
 // cg_global_kernel) -- the reference's own data flow (als.cu:782-831).
 // ----------------------------------------------------------------------------------
-template <int NB, int NW, int W, int MODE>
+template <int NB, int NW, int W, int MODE, int ARITH>
 __device__ __forceinline__ void multi_body(float* smem, const KernelArgs& a, long long begin, int len, int slot,
                                            int row, int rowlen, int lane) {
   constexpr int NT = NB * (NB + 1) / 2;
@@ -956,7 +1032,7 @@ __device__ __forceinline__ void multi_body(float* smem, const KernelArgs& a, lon
     WaveGather<NB> wg;
     wg.init(a, f, begin, len, lane);
     WaveStage<NB> R;
-    Planes<NB> P;
+    Planes<NB, ARITH> P;
     using gptr = const __attribute__((address_space(1))) void*;
     using lptr = __attribute__((address_space(3))) void*;
     auto clamp = [&](int s) { return s < nst ? s : nst - 1; };
@@ -988,7 +1064,7 @@ __device__ __forceinline__ void multi_body(float* smem, const KernelArgs& a, lon
     for (int s = 0; s < nst; ++s) {
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's chunks of stage s (and the indices of s + 1) are here
       __syncthreads();                      // ... and the partner's; everybody is done reading stage s - 1
-      issue_share(clamp(s + 1), (s + 1) & 1);
+      if (s + 1 < nst) issue_share(s + 1, (s + 1) & 1);  // uniform: the last stage prefetches nothing
       const float* lds_lane = smem + (s & 1) * kBuf + lane;
       // chunk -> registers -> planes, block by block (the raw values of one block live at a time)
       static_for<NB>([&](auto bc) {
@@ -997,29 +1073,37 @@ __device__ __forceinline__ void multi_body(float* smem, const KernelArgs& a, lon
           constexpr int E = decltype(ec)::value;
           R.raw[B][E] = lds_lane[64 * (E * NB + B)];
         });
-        if constexpr (B == NB - 1) static_for<8>([&](auto ec) { wg.template finish_one<decltype(ec)::value>(R); });
+        if constexpr (B == NB - 1) static_for<8>([&](auto ec) { wg.template finish_one<decltype(ec)::value, ARITH>(R); });
         static_for<4>([&](auto vc) { split_pair<NB, B, decltype(vc)::value>(R, P); });
       });
-      wg.template load_val<false>(R, clamp(s + 1));
-      wg.template load_idx<false>(R, clamp(s + 2));
-      static_for<6>([&](auto pc) {
+      if (s + 1 < nst) {
+        wg.template load_val<false>(R, s + 1);
+        wg.template load_idx<false>(R, clamp(s + 2));
+      }
+      static_for<gram_products<ARITH>()>([&](auto pc) {
         constexpr int PROD = decltype(pc)::value;
         static_for<TPW>([&](auto sc) {
           constexpr int t = W + NW * decltype(sc)::value;
           if constexpr (t < NT) {
             constexpr int I = tile_I<NB>(t), J = tile_J<NB>(t), sl = decltype(sc)::value;
-            if constexpr (PROD == 0) acc[sl] = mfma_bf16(P.l[I], P.h[J], acc[sl]);
-            if constexpr (PROD == 1) acc[sl] = mfma_bf16(P.h[I], P.l[J], acc[sl]);
-            if constexpr (PROD == 2) acc[sl] = mfma_bf16(P.m[I], P.m[J], acc[sl]);
-            if constexpr (PROD == 3) acc[sl] = mfma_bf16(P.m[I], P.h[J], acc[sl]);
-            if constexpr (PROD == 4) acc[sl] = mfma_bf16(P.h[I], P.m[J], acc[sl]);
-            if constexpr (PROD == 5) acc[sl] = mfma_bf16(P.h[I], P.h[J], acc[sl]);
+            if constexpr (ARITH == kArithFast) {
+              if constexpr (PROD == 0) acc[sl] = mfma_f16(P.l[I], P.h[J], acc[sl]);
+              if constexpr (PROD == 1) acc[sl] = mfma_f16(P.h[I], P.l[J], acc[sl]);
+              if constexpr (PROD == 2) acc[sl] = mfma_f16(P.h[I], P.h[J], acc[sl]);
+            } else {
+              if constexpr (PROD == 0) acc[sl] = mfma_bf16(P.l[I], P.h[J], acc[sl]);
+              if constexpr (PROD == 1) acc[sl] = mfma_bf16(P.h[I], P.l[J], acc[sl]);
+              if constexpr (PROD == 2) acc[sl] = mfma_bf16(P.m[I], P.m[J], acc[sl]);
+              if constexpr (PROD == 3) acc[sl] = mfma_bf16(P.m[I], P.h[J], acc[sl]);
+              if constexpr (PROD == 4) acc[sl] = mfma_bf16(P.h[I], P.m[J], acc[sl]);
+              if constexpr (PROD == 5) acc[sl] = mfma_bf16(P.h[I], P.h[J], acc[sl]);
+            }
           }
         });
       });
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // the last (unused) prefetch must land before the workgroup exits
   }
+  if constexpr (ARITH == kArithFast) fast_unscale<NB, NW, W>(acc, a.fast_flag);
   // a whole row (no slot): the two waves solve it where the tiles are -- 93 KB per row at f = 200 that
   // neither go out to HBM nor come back (measured: 45 GB each way per Netflix X half-iteration)
   if (slot < 0) {
@@ -1041,7 +1125,7 @@ __device__ __forceinline__ void multi_body(float* smem, const KernelArgs& a, lon
   });
 }
 
-template <int NB, int NW, int MODE>
+template <int NB, int NW, int MODE, int ARITH = kArithSplit3>
 __global__ __launch_bounds__(64 * NW, NB >= 10 ? 1 : 2) void als_wave_multi_kernel(const KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63;
@@ -1053,9 +1137,9 @@ __global__ __launch_bounds__(64 * NW, NB >= 10 ? 1 : 2) void als_wave_multi_kern
   const int rowlen = a.item_rowlen[item];
   static_assert(NW == 2, "two waves per item");
   if ((threadIdx.x >> 6) == 0)
-    multi_body<NB, NW, 0, MODE>(smem, a, begin, len, slot, row, rowlen, lane);
+    multi_body<NB, NW, 0, MODE, ARITH>(smem, a, begin, len, slot, row, rowlen, lane);
   else
-    multi_body<NB, NW, 1, MODE>(smem, a, begin, len, slot, row, rowlen, lane);
+    multi_body<NB, NW, 1, MODE, ARITH>(smem, a, begin, len, slot, row, rowlen, lane);
 }
 
 // ----------------------------------------------------------------------------------
@@ -1125,23 +1209,24 @@ hipError_t wave_solve_launch<CUMF_WAVE_NB>(const KernelArgs& a, int mode, long n
 // ----------------------------------------------------------------------------------
 // Launcher (called by launch_half_iteration, als_kernels.hip)
 // ----------------------------------------------------------------------------------
-template <int NB, int FC>
+template <int NB, int FC, int ARITH>
 static hipError_t launch_wave_fc(const KernelArgs& a, int mode, long n_items, hipStream_t stream) {
   const size_t stage_lds = wave_stage_lds_floats<NB>() * sizeof(float);
   if (mode == kModeMaterialize) {
-    hipLaunchKernelGGL((als_wave_kernel<NB, kModeMaterialize, FC>), dim3((unsigned)n_items), dim3(64), stage_lds, stream,
-                       a);
+    if constexpr (ARITH != kArithSplit3) return hipErrorInvalidValue;  // materialise: the 24-bit arithmetic only
+    hipLaunchKernelGGL((als_wave_kernel<NB, kModeMaterialize, FC, kArithSplit3>), dim3((unsigned)n_items), dim3(64),
+                       stage_lds, stream, a);
   } else if (mode == kModeCG) {
-    hipLaunchKernelGGL((als_wave_kernel<NB, kModeCG, FC>), dim3((unsigned)n_items), dim3(64), stage_lds, stream, a);
+    hipLaunchKernelGGL((als_wave_kernel<NB, kModeCG, FC, ARITH>), dim3((unsigned)n_items), dim3(64), stage_lds, stream, a);
   } else {
     const size_t lu_lds = wave_lu_lds_floats<NB>(a.f) * sizeof(float);
     const size_t lds = lu_lds > stage_lds ? lu_lds : stage_lds;
     if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(als_wave_kernel<NB, kModeLU, FC>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(als_wave_kernel<NB, kModeLU, FC, ARITH>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((als_wave_kernel<NB, kModeLU, FC>), dim3((unsigned)n_items), dim3(64), lds, stream, a);
+    hipLaunchKernelGGL((als_wave_kernel<NB, kModeLU, FC, ARITH>), dim3((unsigned)n_items), dim3(64), lds, stream, a);
   }
   return hipGetLastError();
 }
@@ -1160,20 +1245,32 @@ hipError_t wave_item_launch<CUMF_WAVE_NB>(const KernelArgs& a, int mode, long n_
   // als_lu_wg.h with two wave roles), items with one dump their tiles
   size_t lds = 2 * wave_stage_lds_floats<CUMF_WAVE_NB>() * sizeof(float);  // double-buffered stages
   if (lu_wg_lds_floats<CUMF_WAVE_NB>(a.f) * sizeof(float) > lds) lds = lu_wg_lds_floats<CUMF_WAVE_NB>(a.f) * sizeof(float);
-  if (mode == kModeCG)
+  if (a.fast_words) {
+    if (mode == kModeMaterialize) return hipErrorInvalidValue;
+    if (mode == kModeCG)
+      hipLaunchKernelGGL((als_wave_multi_kernel<CUMF_WAVE_NB, 2, kModeCG, kArithFast>), dim3((unsigned)n_items),
+                         dim3(128), lds, stream, a);
+    else
+      hipLaunchKernelGGL((als_wave_multi_kernel<CUMF_WAVE_NB, 2, kModeLU, kArithFast>), dim3((unsigned)n_items),
+                         dim3(128), lds, stream, a);
+  } else if (mode == kModeCG) {
     hipLaunchKernelGGL((als_wave_multi_kernel<CUMF_WAVE_NB, 2, kModeCG>), dim3((unsigned)n_items), dim3(128), lds,
                        stream, a);
-  else
+  } else {
     hipLaunchKernelGGL((als_wave_multi_kernel<CUMF_WAVE_NB, 2, kModeLU>), dim3((unsigned)n_items), dim3(128), lds,
                        stream, a);
+  }
   return hipGetLastError();
 #else
   if (mode != kModeMaterialize && mode != kModeLU && mode != kModeCG) return hipErrorInvalidValue;
 #if CUMF_WAVE_NB == 7 && !(CUMF_WAVE_VARIANT & 2)
   // the reference's own specialisation: get_hermitian100 for f == 100 (als.cu:788-817)
-  if (a.f == 100) return launch_wave_fc<7, 100>(a, mode, n_items, stream);
+  if (a.f == 100)
+    return a.fast_words ? launch_wave_fc<7, 100, kArithFast>(a, mode, n_items, stream)
+                        : launch_wave_fc<7, 100, kArithSplit3>(a, mode, n_items, stream);
 #endif
-  return launch_wave_fc<CUMF_WAVE_NB, 0>(a, mode, n_items, stream);
+  return a.fast_words ? launch_wave_fc<CUMF_WAVE_NB, 0, kArithFast>(a, mode, n_items, stream)
+                      : launch_wave_fc<CUMF_WAVE_NB, 0, kArithSplit3>(a, mode, n_items, stream);
 #endif
 }
 

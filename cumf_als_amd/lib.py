@@ -18,7 +18,7 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 # every extern "C" symbol declared in include/cumf_als_capi.h
 C_SYMBOLS = [
-    "cumf_doALS", "cumf_doALS_ex", "cumf_plan_create", "cumf_plan_destroy", "cumf_plan_info",
+    "cumf_doALS", "cumf_doALS_ex", "cumf_plan_create", "cumf_plan_destroy", "cumf_plan_info", "cumf_plan_set_gather_rows", "cumf_gram_fast_status",
     "cumf_fused_available", "cumf_als_update_fused", "cumf_get_hermitian", "cumf_get_hermitian_fp16", "cumf_cg_solve_batched_fp16", "cumf_set_tt_fp16", "cumf_get_tt_fp16", "cumf_cg_solve_batched", "cumf_lu_solve_batched",
     "cumf_pack_upper", "cumf_unpack_upper", "cumf_sse", "cumf_set_gram_mode", "cumf_get_gram_mode", "cumf_check_gather_table", "cumf_set_kernel_timing", "cumf_last_kernel_ms", "cumf_rand_init", "cumf_als_version", "cumf_als_arch",
 ]
@@ -62,6 +62,10 @@ def load():
     lib.cumf_plan_destroy.argtypes = [C.c_void_p]
     lib.cumf_plan_info.restype = C.c_int
     lib.cumf_plan_info.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
+    lib.cumf_plan_set_gather_rows.restype = C.c_int
+    lib.cumf_plan_set_gather_rows.argtypes = [C.c_void_p, C.c_long]
+    lib.cumf_gram_fast_status.restype = C.c_int
+    lib.cumf_gram_fast_status.argtypes = [C.POINTER(C.c_int)]
     lib.cumf_fused_available.restype = C.c_int
     lib.cumf_fused_available.argtypes = [C.c_int, C.c_int]
     lib.cumf_als_update_fused.restype = C.c_int

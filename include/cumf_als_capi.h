@@ -157,7 +157,19 @@ int cumf_sse(const float* val, const int* row, const int* col, const float* thet
  * Process-wide; also settable with the environment variable CUMF_ALS_GRAM=split|exact read at the
  * first half-iteration.
  */
-enum { CUMF_GRAM_AUTO = 0, CUMF_GRAM_EXACT = 1 };
+enum { CUMF_GRAM_AUTO = 0, CUMF_GRAM_EXACT = 1, CUMF_GRAM_FAST = 2 };
+/*
+ *   CUMF_GRAM_FAST  (opt-in; CUMF_ALS_GRAM=fast) the fused LU / CG passes of the wave kernels read a
+ *                   PRE-SPLIT copy of the factor table, one (h, l) pair of f16 per value with
+ *                   4096 x ~ h + l to 2^-22, and form each product from three f16 products (hh + hl + lh,
+ *                   fp32 accumulation): 22 significand bits instead of 24, half the matrix-pipe work of
+ *                   CUMF_GRAM_AUTO.  Needs the row count of the gather table (cumf_plan_set_gather_rows)
+ *                   and factors and ratings below 15.99 in magnitude; violations are detected on the
+ *                   device and reported by cumf_gram_fast_status (bit 0: a factor, bit 1: a rating).
+ *                   Everything else (materialise, f <= 14) runs as CUMF_GRAM_AUTO.
+ */
+int cumf_plan_set_gather_rows(cumf_plan_t* plan, long gather_rows);
+int cumf_gram_fast_status(int* flags);
 /* 0 when a table of gather_rows x f floats can be gathered by the kernels that (solver, f,
  * materialize) select; an error (message on stderr) when that path addresses the table with 32-bit
  * byte offsets and the table is 4 GiB or larger.  doALS and the Python wrappers call it. */

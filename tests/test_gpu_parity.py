@@ -87,6 +87,70 @@ def test_split_gram_error_class(oracle, alslib, f):
     assert err["auto"][1] <= 3 * err["exact"][1] + 5e-8, err
 
 
+@pytest.mark.parametrize("f", [20, 64, 100, 128, 200])
+def test_fast_gram_error_class(oracle, alslib, f):
+    """Opt-in gram mode "fast" (pre-split (h, l) f16 pairs, products hh + hl + lh, 22 significand bits):
+    the LU solution of a half-iteration against the fp64 solution of the fp64 normal equations must stay
+    in the fp32 class -- within 1e-5 relative and within 4x the distance of the default (24-bit) arithmetic
+    -- and the range flags must stay clear."""
+    _need_gpu()
+    from cumf_als_amd import als
+
+    r = _dataset(96, 400, 9000, 300, seed=f, row_alpha=1.2)
+    d = r.numpy()
+    theta = _factors(r.n, f, 1)
+    lam = 0.05
+    tt64, b64 = oracle.gram_rhs(d["csr_indptr"], d["csr_indices"], d["csr_data"], theta, f, lam, dtype=np.float64)
+    x64 = np.linalg.solve(tt64, b64[..., None])[..., 0]
+    rg = r.to("cuda")
+    th = torch.from_numpy(theta).cuda()
+    plan = als.Plan(d["csr_indptr"], f)
+    err = {}
+    try:
+        for mode in ("auto", "fast"):
+            als.set_gram_mode(mode)
+            x = torch.zeros((r.m, f), device="cuda")
+            als.update_fused(plan, rg.csr_indices, rg.csr_data, th, x, lam, "lu", 6)
+            torch.cuda.synchronize()
+            err[mode] = np.abs(x.cpu().numpy() - x64).max() / np.abs(x64).max()
+        assert als.gram_fast_status() == 0
+    finally:
+        als.set_gram_mode("auto")
+    assert err["fast"] <= 1e-5, err
+    assert err["fast"] <= 4 * err["auto"] + 1e-6, err
+
+
+def test_fast_gram_range_flags(alslib):
+    """Gram mode "fast" reports, on the device, a factor (bit 0) or a rating (bit 1) that leaves the f16
+    range of the pre-split words (|value| >= 15.99) instead of returning silently wrong factors."""
+    _need_gpu()
+    from cumf_als_amd import als
+
+    f = 32
+    r = _dataset(64, 80, 2000, 100, seed=3)
+    d = r.numpy()
+    rg = r.to("cuda")
+    plan = als.Plan(d["csr_indptr"], f)
+    try:
+        als.set_gram_mode("fast")
+        als.gram_fast_status()
+        theta = _factors(r.n, f, 2)
+        x = torch.zeros((r.m, f), device="cuda")
+        als.update_fused(plan, rg.csr_indices, rg.csr_data, torch.from_numpy(theta).cuda(), x, 0.05, "lu", 6)
+        assert als.gram_fast_status() == 0
+        big = theta.copy()
+        big[5, 3] = 40.0
+        als.update_fused(plan, rg.csr_indices, rg.csr_data, torch.from_numpy(big).cuda(), x, 0.05, "lu", 6)
+        assert als.gram_fast_status() & 1
+        vals = rg.csr_data.clone()
+        vals[7] = 100.0
+        als.update_fused(plan, rg.csr_indices, vals, torch.from_numpy(theta).cuda(), x, 0.05, "lu", 6)
+        assert als.gram_fast_status() & 2
+        assert als.gram_fast_status() == 0  # reading clears
+    finally:
+        als.set_gram_mode("auto")
+
+
 def test_long_row_many_slots(oracle, alslib):
     """A row of 210 000 ratings (Netflix X-side scale: rows of 10^5 ratings cut into ~100 chunks, the
     reduce kernel summing ~100 partial tile sets in slot order) against the fp64 oracle."""
@@ -207,7 +271,7 @@ def test_cg_solve(oracle, alslib, f):
     assert (np.abs(res_h - res_o) <= 1e-4 * np.linalg.norm(b64, axis=1)).all(), np.abs(res_h - res_o).max()
 
 
-@pytest.mark.parametrize("gram_mode", ["exact", "auto"], indirect=True)
+@pytest.mark.parametrize("gram_mode", ["exact", "auto", "fast"], indirect=True)
 @pytest.mark.parametrize("solver,f", [("cg", 10), ("cg", 100), ("cg", 128), ("lu", 10), ("lu", 100), ("lu", 128),
                                       ("lu", 200), ("lu", 98), ("lu", 110), ("lu", 96), ("lu", 206), ("cg", 98)])
 def test_fused_half_iteration(oracle, alslib, gram_mode, solver, f):
@@ -286,7 +350,7 @@ def test_doals_large_f(oracle, alslib, f, solver):
         assert abs(rm - rm_o) <= max(1e-4, floor)
 
 
-@pytest.mark.parametrize("gram_mode", ["exact", "auto"], indirect=True)
+@pytest.mark.parametrize("gram_mode", ["exact", "auto", "fast"], indirect=True)
 @pytest.mark.parametrize("shape", [(400, 300, 40000, 3000, 20), (300, 200, 6000, 700, 20)])
 def test_sse_and_doals_rmse(oracle, alslib, gram_mode, shape):
     """Full doALS (5 iterations) vs the oracle.  LU: factors bit-identical.  CG: RMSE
