@@ -373,11 +373,25 @@ __device__ __forceinline__ void stage_step(const WaveGather<NB>& wg, Planes<NB, 
   wg.dma_read(R, lds_lane);
   static_for<8>([&](auto ec) { wg.template finish_one<decltype(ec)::value, ARITH>(R); });  // consumes R.rv
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the chunks are in registers, the buffer is free
-  if constexpr (KIND != kStepLast) {
-    constexpr bool FULL = KIND == kStepFull;
-    if (!(wg.dbg & 16)) wg.template dma_issue<FULL>(R, lds, s_next);  // consumes R.idx
-    wg.template load_val<FULL>(R, s_next);
-    wg.template load_idx<FULL>(R, s_idx);
+  if constexpr (KIND == kStepFull) {
+    if (!(wg.dbg & 16)) wg.template dma_issue<true>(R, lds, s_next);  // consumes R.idx
+    wg.template load_val<true>(R, s_next);
+    wg.template load_idx<true>(R, s_idx);
+  } else if constexpr (KIND == kStepPartial) {
+    // the last steps of an item: wave-uniform choices between the select-free and the clamped forms
+    // (every step waits for vmcnt(0) anyway, so loads under a uniform branch cost nothing extra)
+    const int nfull = wg.len / kWaveStage, nst = (wg.len + kWaveStage - 1) / kWaveStage;
+    if (s_next < nfull) {
+      wg.template dma_issue<true>(R, lds, s_next);
+      wg.template load_val<true>(R, s_next);
+    } else {
+      wg.template dma_issue<false>(R, lds, s_next);
+      wg.template load_val<false>(R, s_next);
+    }
+    if (s_idx < nfull)
+      wg.template load_idx<true>(R, s_idx);
+    else if (s_idx < nst)
+      wg.template load_idx<false>(R, s_idx);
   }
   static_for<4 * NB>([&](auto uc) { split_pair<NB, decltype(uc)::value / 4, decltype(uc)::value % 4>(R, P); });
   static_for<gram_products<ARITH>()>([&](auto pc) { gram_product<NB, decltype(pc)::value>(P, acc); });
@@ -976,7 +990,7 @@ __global__ __launch_bounds__(64, CUMF_WAVE_MIN_WAVES) void als_wave_kernel(const
     // stages s + 1, s + 2 full: select-free steps; then the clamped form; the last stage of the item
     // prefetches nothing (three step bodies, each branch-free)
     for (; s + 2 < nfull; ++s) stage_step<NB, kStepFull, ARITH>(wg, P, R, lds, lds_lane, acc, s + 1, s + 2);
-    for (; s + 1 < nst; ++s) stage_step<NB, kStepPartial, ARITH>(wg, P, R, lds, lds_lane, acc, s + 1, clamp(s + 2));
+    for (; s + 1 < nst; ++s) stage_step<NB, kStepPartial, ARITH>(wg, P, R, lds, lds_lane, acc, s + 1, s + 2);
     stage_step<NB, kStepLast, ARITH>(wg, P, R, lds, lds_lane, acc, 0, 0);  // the last stage prefetches nothing
   }
   if constexpr (ARITH == kArithFast) fast_unscale<NB, 1, 0>(acc, a.fast_flag);
