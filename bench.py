@@ -151,6 +151,54 @@ def measured_traffic():
         return None
 
 
+def fast_leg(r, f, lam, a, theta0, eng_default):
+    """Informational, outside the timed region of `value`: the same steps in the OPT-IN gram mode "fast"
+    (pre-split f16x2 operands, 3 MFMA products per fp32 product, 22 significand bits),
+    plus the distance of one X and one Theta half-iteration from the default arithmetic on the same inputs."""
+    import torch
+
+    from cumf_als_amd import als
+
+    als.set_gram_mode("fast")
+    try:
+        eng = als.ALSEngine(r, f, lam, solver=a.solver, cg_iters=a.cg_iters)
+        eng.init_factors(theta0)
+        for _ in range(max(1, a.warmup)):
+            eng.update_x()
+            eng.update_theta()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            eng.update_x()
+            eng.update_theta()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / a.steps
+        flags = als.gram_fast_status()
+        tr, te = eng.rmse()
+        # same inputs, both arithmetics: the default engine's current factors
+        eng.thetaT.copy_(eng_default.thetaT)
+        eng.XT.copy_(eng_default.XT)
+        eng.update_x()
+        x_fast = eng.XT.clone()
+        eng.XT.copy_(eng_default.XT)
+        eng.update_theta()
+        th_fast = eng.thetaT.clone()
+        als.set_gram_mode("auto")
+        keep_x, keep_t = eng_default.XT.clone(), eng_default.thetaT.clone()
+        eng_default.update_x()
+        dx = float((x_fast - eng_default.XT).abs().max() / eng_default.XT.abs().max())
+        eng_default.XT.copy_(keep_x)
+        eng_default.update_theta()
+        dth = float((th_fast - eng_default.thetaT).abs().max() / eng_default.thetaT.abs().max())
+        eng_default.thetaT.copy_(keep_t)
+        return {"opt_in": "CUMF_ALS_GRAM=fast / cumf_set_gram_mode(CUMF_GRAM_FAST)", "ms_per_step": 1e3 * dt,
+                "value": 2.0 * r.nnz / dt, "unit": "ratings/s", "range_flags": flags,
+                "rmse": {"train": tr, "test": te, "after_iterations": max(1, a.warmup) + a.steps},
+                "x_half_iteration_max_rel_vs_default": dx, "theta_half_iteration_max_rel_vs_default": dth}
+    finally:
+        als.set_gram_mode("auto")
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -162,6 +210,7 @@ def main() -> int:
     ap.add_argument("--solver", default="lu", choices=["lu", "cg"])
     ap.add_argument("--cg-iters", type=int, default=6)
     ap.add_argument("--scheme", default="gather", choices=["gather", "reduce"])
+    ap.add_argument("--no-fast-leg", action="store_true", help="skip the informational opt-in fast-mode leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
     a = ap.parse_args()
@@ -320,14 +369,18 @@ def main() -> int:
         avg_bytes = 0.5 * (bx + bt)
         achieved = avg_bytes / (avg_ms * 1e-3) / 1e9
         mode = als.get_gram_mode()
-        wave = mode == "auto" and not cg and f <= 111
-        kernel = (f"cumf::als_wave_kernel<{f // 16 + 1}, LU, {100 if f == 100 else 0}>" if wave
-                  else f"cumf::als_item_kernel<{f // 16 + 1}, float4, {'CG' if cg else 'LU'}>")
-        traffic = measured_traffic() or {}
         nb = f // 16 + 1
+        wave = mode in ("auto", "fast") and 2 <= nb <= 13
+        sv = "CG" if cg else "LU"
+        kernel = ((f"cumf::als_wave_kernel<{nb}, {sv}, {100 if f == 100 else 0}>" if nb <= 7
+                   else f"cumf::als_wave_multi_kernel<{nb}, 2, {sv}>") if wave
+                  else f"cumf::als_item_kernel<{nb}, float4, {sv}>")
+        traffic = measured_traffic() or {}
         # matrix-pipe work ISSUED per rating: upper-triangular 16x16 tiles x 2*16*16 flops, x6 bf16
-        # products on the split path (als_wave.hip) / x1 on the fp32 MFMA path
-        issued = nb * (nb + 1) / 2 * 512.0 * (6 if wave else 1)
+        # products on the split path (als_wave.hip), x3 f16 products in the opt-in fast mode, x1 on the
+        # fp32 MFMA path
+        products = (3 if mode == "fast" else 6) if wave else 1
+        issued = nb * (nb + 1) / 2 * 512.0 * products
         pipe_peak = 2500.0 if wave else MFMA_F32_PEAK_TFLOPS
 
         def side(ms, nbytes, key):
@@ -338,7 +391,9 @@ def main() -> int:
                     "matrix_pipe_frac_issued": float(nnz) * issued / (ms * 1e-3) / 1e12 / pipe_peak}
 
         xs, ts = sum(x_ms) / len(x_ms), sum(t_ms) / len(t_ms)
-        out["dtype"] = "f32 (bf16x3-split products on the bf16 matrix pipe, fp32 accumulate)" if wave else "f32"
+        out["dtype"] = ("f32" if not wave else
+                        "f32 (opt-in fast mode: pre-split f16x2 operands, 3 products, 22-bit significand, fp32 accumulate)"
+                        if mode == "fast" else "f32 (bf16x3-split products on the bf16 matrix pipe, fp32 accumulate)")
         out["roofline"] = {
             "bound": "hbm", "kernel": kernel,
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -352,7 +407,8 @@ def main() -> int:
             "gram_tflops": float(nnz) * f * (f + 1) / (avg_ms * 1e-3) / 1e12,
             # the matrix pipe next to the HBM roof: flops issued (tile padding and, on the split path,
             # the six bf16 products per fp32 product included) against the pipe's dense peak
-            "mfma": {"bound": "mfma", "pipe": "bf16 (6 products per fp32 product)" if wave else "fp32",
+            "mfma": {"bound": "mfma", "pipe": (f"{'f16' if mode == 'fast' else 'bf16'} ({products} products per fp32 product)"
+                                                if wave else "fp32"),
                      "achieved": float(nnz) * issued / (avg_ms * 1e-3) / 1e12, "peak": pipe_peak, "unit": "TFLOP/s",
                      "frac": float(nnz) * issued / (avg_ms * 1e-3) / 1e12 / pipe_peak},
             # what a perfect kernel of this design would take: the larger of the HBM time of the
@@ -361,6 +417,8 @@ def main() -> int:
         }
         tr, te = eng.rmse()
         out["rmse"] = {"train": tr, "test": te, "after_iterations": a.warmup + a.steps + len(x_ms)}
+        if mode == "auto" and wave and not a.no_fast_leg:
+            out["gram_fast_mode"] = fast_leg(r, f, lam, a, theta0, eng)
         if not a.no_cpu_baseline:
             d = {k: v for k, v in r.numpy().items() if k.startswith("cs")}
             oracle_out, out["cpu_baseline"] = cpu_baseline(d, f, lam, a.solver)
