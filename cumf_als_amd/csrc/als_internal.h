@@ -99,9 +99,9 @@ hipError_t launch_half_iteration(const KernelArgs& a, int mode, long n_items, lo
 hipError_t launch_solve_batched(const float* A, const float* b, float* x, long batch, int f, int mode, int cg_iters,
                                 hipStream_t stream);
 // Gram arithmetic of the fused / materialising passes.
-//   kGramSplit: fp32 values split exactly into three bf16 terms, six bf16 MFMA products per fp32
+//   kGramAuto:  fp32 values split exactly into three bf16 terms, six bf16 MFMA products per fp32
 //               product, fp32 accumulation (als_wave.hip; fp32-class error, not bit-identical to a
-//               fmaf chain); used where the wave-per-item kernels exist (LU and materialise, f <= 111),
+//               fmaf chain); used where the wave kernels exist (all solvers and materialise, 16 <= f <= 207),
 //   kGramExact: v_mfma_f32_16x16x4_f32, bit-identical to the reference thread's fmaf chain.
 //   kGramFast (opt-in): the factor table pre-split into (h, l) f16 pairs of 4096 x, three f16 MFMA
 //               products per fp32 product (22 significand bits); fused LU / CG passes of the wave

@@ -1,16 +1,18 @@
-// als_wave.hip -- wave-per-item ALS half-iteration kernels for gfx950 (f <= 128).
+// als_wave.hip -- wave-level ALS half-iteration kernels for gfx950 (16 <= f <= 207).
 //
 // Same job as als_item_kernel (als_kernels.hip) -- RHS + Gram + solve of one plan item,
 // replacing cusparseScsrmm2 + cublasSgeam (als.cu:750-757), get_hermitian100 /
-// get_hermitianT10 (als.cu:443-569 / 575-659) and the batched LU (als.cu:58-189) -- with a
-// different mapping onto the chip:
+// get_hermitianT10 (als.cu:443-569 / 575-659), the batched LU (als.cu:58-189) and the CG of
+// cg.cu:36-231 -- with a different mapping onto the chip:
 //
-//   * ONE wave owns one item and all NB (NB + 1) / 2 upper-triangular 16 x 16 accumulator
-//     tiles of its system.  No workgroup barrier anywhere, no staging through LDS: every
+//   * als_wave_kernel (NB = 2 .. 7, f <= 111): ONE wave owns one item and all NB (NB + 1) / 2
+//     upper-triangular 16 x 16 accumulator tiles of its system.  No workgroup barrier anywhere: every
 //     lane gathers straight into the MFMA operand layout -- lane (g, c) = (lane >> 4, lane & 15)
-//     loads feature 16 b + c of the eight ratings 8 g .. 8 g + 7 of a 32-rating stage, one
-//     4-byte load per (feature block b, rating): a wave instruction touches four 64-byte
-//     segments of four gathered factor rows.  64-bit lane addresses: no 4 GiB table limit.
+//     fetches feature 16 b + c of the eight ratings 8 g .. 8 g + 7 of a 32-rating stage, one
+//     4-byte global_load_lds_dword per (feature block b, rating): a wave instruction touches four
+//     64-byte segments of four gathered factor rows and lands as one 256-byte chunk in LDS, a full
+//     stage ahead of its use and without holding registers.  64-bit lane addresses: no 4 GiB limit.
+//     als_wave_multi_kernel (NB = 8 .. 13): two waves per item share the chunks and split the tiles.
 //   * fp32 on the bf16 matrix pipe.  The fp32 MFMA runs at 1/16 of the bf16 rate, and a
 //     16-wide tiling of a 101-column system computes 1.42x the useful flops: at 157 TF that is
 //     9.1 ms per Netflix half-iteration against 5.05 ms of HBM time.  Here every
@@ -21,12 +23,15 @@
 //     below the rounding error of one fp32 fmaf on a sum of two such products.  Every bf16
 //     product is exact in fp32.  Error against an fp64 Gram is the same class as the fmaf
 //     chain's (tests/test_gpu_parity.py::test_split_gram_error_class); the bit-exact fp32
-//     MFMA path stays available (cumf_set_gram_mode / CUMF_ALS_GRAM=exact).
-//   * LU on the accumulators of the one wave: four pivots per step as one rank-4
-//     v_mfma_f32_16x16x4_f32 per live tile (the elimination of lu_solve_mfma, als_kernels.hip),
+//     MFMA path stays available (cumf_set_gram_mode / CUMF_ALS_GRAM=exact), and an opt-in 22-bit
+//     arithmetic on pre-split f16 pairs (kArithFast, CUMF_ALS_GRAM=fast) halves the matrix-pipe work.
+//   * LU on the accumulators of the one wave (lu_wave): four pivots per step as one rank-4
+//     v_mfma_f32_16x16x4_f32 per live tile (the elimination of lu_solve_mfma, als_lu_wg.h),
 //     but the 4 x 4 pivot block comes from v_readlane, the panel rows reach the other lane
 //     groups through ds_bpermute_b32, and nothing waits on another wave.  Back substitution
-//     on the packed row store (back_substitute_zeroed, als_device.h).
+//     straight from the tiles through a 16-column LDS window (back_substitute_tiles).
+//   * CG on the accumulators (cg_wave_core): vectors in a column layout, the mat-vec on the upper
+//     tiles with DPP / ds_bpermute reductions, 1, 2 or 4 waves per system.
 //
 // The accumulator layout (C/D of every 16 x 16 MFMA: lane (g, c), register r = element
 // (4 g + r, c)) and the partial-tile scratch layout are those of als_kernels.hip, so chunked

@@ -148,13 +148,13 @@ int cumf_sse(const float* val, const int* row, const int* col, const float* thet
  * Arithmetic of the Gram pass (the reference chooses its variants at compile time too:
  * `#define CUMF_USE_HALF` / CUMF_TT_FP16, als.cu:25-33).
  *   CUMF_GRAM_AUTO  (default) fp32 evaluated on the bf16 matrix pipe where a kernel for it exists
- *                   (LU solver and the materialising pass, 16 <= f <= 111): every gathered fp32 value is
+ *                   (LU, CG and the materialising pass, 16 <= f <= 207): every gathered fp32 value is
  *                   split EXACTLY into three bf16 terms and each product is formed from six bf16
  *                   products with fp32 accumulation; the dropped terms are < 2^-23 of a product.
  *                   fp32-class error against an fp64 Gram, not bit-identical to get_hermitian's
  *                   fmaf chain (als.h:39-143).  Everything else runs CUMF_GRAM_EXACT.
  *   CUMF_GRAM_EXACT v_mfma_f32_16x16x4_f32: bit-identical to the reference thread's fmaf chain.
- * Process-wide; also settable with the environment variable CUMF_ALS_GRAM=split|exact read at the
+ * Process-wide; also settable with the environment variable CUMF_ALS_GRAM=split|exact|fast read at the
  * first half-iteration.
  */
 enum { CUMF_GRAM_AUTO = 0, CUMF_GRAM_EXACT = 1, CUMF_GRAM_FAST = 2 };
