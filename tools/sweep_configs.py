@@ -40,6 +40,8 @@ if what in ("all", "quick"):
     run("netflix", 100, "cg")
     run("netflix", 100, "lu")
     run("netflix", 100, "lu", gram="exact")
+    run("netflix", 100, "lu", gram="fast")
+    run("netflix", 100, "cg", gram="fast")
     run("netflix", 100, "lu", fused=False, theta_batch=3)
 if what in ("all", "f200"):
     run("netflix", 128, "lu")
@@ -48,4 +50,5 @@ if what in ("all", "f200"):
     run("netflix", 160, "cg", iters=1)
     run("netflix", 200, "cg", iters=1)
     run("netflix", 200, "lu", iters=1)
+    run("netflix", 200, "cg", iters=1, gram="fast")
     run("netflix", 200, "cg", fused=False, theta_batch=10, iters=1)
