@@ -28,12 +28,13 @@ class OracleOps:
         return _Plan(rowptr, f, row_begin, row_end)
 
     def update_fused(self, plan, colidx, val, gather, update, lam, solver, cg_iters):
-        out = update.numpy()
-        assert plan.row_begin == 0 and plan.row_end == len(plan.rowptr) - 1
-        x = np.ascontiguousarray(out, np.float32)
-        pyoracle.half_iteration(plan.rowptr, colidx.numpy(), val.numpy(), gather.numpy(), x, plan.f, lam,
-                                solver=solver, cg_iters=cg_iters)
-        update.copy_(torch.from_numpy(x))
+        b, e = plan.row_begin, plan.row_end   # a plan may cover a sub-range of the rows (batches, pipeline pieces)
+        rp = plan.rowptr[b:e + 1] - plan.rowptr[b]
+        s0, s1 = int(plan.rowptr[b]), int(plan.rowptr[e])
+        x = np.ascontiguousarray(update.numpy()[b:e], np.float32)
+        pyoracle.half_iteration(np.ascontiguousarray(rp), colidx.numpy()[s0:s1], val.numpy()[s0:s1], gather.numpy(), x,
+                                plan.f, lam, solver=solver, cg_iters=cg_iters)
+        update[b:e].copy_(torch.from_numpy(x))
 
     def get_hermitian(self, plan, colidx, val, gather, lam, tt, rhs):
         A, b = pyoracle.gram_rhs(plan.rowptr, colidx.numpy(), val.numpy(), gather.numpy(), plan.f, lam,

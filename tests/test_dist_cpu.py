@@ -126,3 +126,56 @@ def test_hugewiki_runner_from_split_files(tmp_path, solver):
     log = np.array(outs[0][3])
     assert np.abs(log - np.asarray(log_o)).max() <= 1e-4, (log, log_o)
     assert np.abs(outs[0][1] - th0.reshape(n, f)).max() <= 2e-3 * max(1.0, np.abs(th0).max())
+
+
+def test_pipeline_bounds_and_row_map():
+    """The pipelined all-gather of the X update (dist.PipelinedGather): every rank's slab in nnz-balanced
+    pieces, computed identically everywhere; the row map sends every global row to exactly one slot of the
+    padded receive buffer."""
+    import numpy as np
+    import torch
+
+    from cumf_als_amd import dist as cdist
+
+    rng = np.random.RandomState(0)
+    lens = rng.randint(0, 50, size=1000)
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    for world, chunks in ((2, 4), (8, 4), (3, 1), (5, 7)):
+        xb = cdist.balanced_slabs(rowptr, world)
+        pb = cdist.pipeline_bounds(rowptr, xb, chunks)
+        assert pb.shape == (world, chunks + 1)
+        assert (pb[:, 0] == xb[:-1]).all() and (pb[:, -1] == xb[1:]).all()
+        assert (np.diff(pb, axis=1) >= 0).all()
+        g = cdist.PipelinedGather(pb, 1000, 3, torch.float32, torch.device("cpu"))
+        idx = g.idx.numpy()
+        assert len(np.unique(idx)) == 1000 and idx.max() < g.recv.shape[0]
+        # emulate the collectives: piece c of rank r lands at off[c] + r * mx[c]
+        full = torch.arange(3000, dtype=torch.float32).reshape(1000, 3)
+        for c in range(chunks):
+            for r in range(world):
+                lo, hi = int(pb[r, c]), int(pb[r, c + 1])
+                base = int(g.off[c]) + r * g.mx[c]
+                g.recv[base: base + hi - lo] = full[lo:hi]
+        out = torch.empty_like(full)
+        g.finish(out)
+        assert torch.equal(out, full)
+
+
+def test_world2_pipelined_gather_equals_blocking(monkeypatch):
+    """gather scheme, 2 ranks: the pipelined X all-gather (default, 4 pieces) and the blocking one
+    (CUMF_ALS_PIPE_CHUNKS=1) give bit-identical factors."""
+    import numpy as np
+
+    from cumf_als_amd import datagen
+
+    m, n, f, lam, iters = 70, 50, 10, 0.05, 2
+    r = datagen.synth_ratings(m, n, 2600, 300, seed=13, row_alpha=1.1)
+    d = {k: v for k, v in r.numpy().items()}
+    theta0 = (0.2 * np.random.RandomState(0).random_sample((n, f))).astype(np.float32)
+    res = {}
+    for chunks in ("4", "1"):
+        monkeypatch.setenv("CUMF_ALS_PIPE_CHUNKS", chunks)  # inherited by the spawned ranks
+        res[chunks] = _run(2, "gather", "lu", d, m, n, f, lam, iters, 1, theta0)
+    for a, b in zip(res["4"], res["1"]):
+        np.testing.assert_array_equal(a[1], b[1])
+        np.testing.assert_array_equal(a[2], b[2])

@@ -104,6 +104,7 @@ def _rccl_worker(port, scheme, solver, d, m, n, f, lam, iters, theta0, q):
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["CUMF_ALS_PIPE_FORCE"] = "1"  # the pipelined (async) all-gather of the X update, on one rank
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
@@ -120,6 +121,8 @@ def _rccl_worker(port, scheme, solver, d, m, n, f, lam, iters, theta0, q):
                                    d["csc_indices"], d["csc_data"])
             eng = cdist.DistALS(mat, f, lam, cdist.HipOps("cuda:0"), solver=solver, cg_iters=6, scheme=scheme,
                                 theta_batch=3)
+        if scheme.startswith("gather"):
+            assert eng._px is not None and eng._px.chunks == 4 and not eng._px.staged
         eng.init_factors(theta0)
         eng.iterate(iters)
         torch.cuda.synchronize()
