@@ -328,8 +328,12 @@ __device__ __forceinline__ void tiles_to_global(const f32x4 (&acc)[Geo<NB>::TPW]
         float v = acc[s][r];
         if (i < f && j < f) {
           if (i == j) v += reg;
-          tt[(size_t)i * f + j] = (T)v;  // T = _Float16: round to nearest even, as __float2half_rn (als.h:373-499)
-          if (I != J) tt[(size_t)j * f + i] = (T)v;
+          // both triangles from one accumulator entry (tiles summed from the split path are not bit-symmetric
+          // inside a diagonal tile; als.h:39-143 mirrors one temp as well)
+          if (I != J || i <= j) {
+            tt[(size_t)i * f + j] = (T)v;  // T = _Float16: round to nearest even, as __float2half_rn (als.h:373-499)
+            if (i != j) tt[(size_t)j * f + i] = (T)v;
+          }
         } else if (i < f && j == f && rhs != nullptr) {
           rhs[i] = v;
         }

@@ -106,7 +106,10 @@ extern "C" int cumf_plan_create(cumf_plan_t** out, const void* rowptr_host, int 
     return rowptr_is_64 ? static_cast<const long long*>(rowptr_host)[i]
                         : static_cast<long long>(static_cast<const int*>(rowptr_host)[i]);
   };
-  if (chunk <= 0) chunk = default_chunk(f, rp(row_end) - rp(row_begin));
+  // from the ratings of the WHOLE row pointer, not of [row_begin, row_end): the X_BATCH / THETA_BATCH plans
+  // of one side then cut their heavy rows alike and a batched run stays bit-identical to the unbatched
+  // one (als.cu:768-777; tests/test_gpu_fullsize.py)
+  if (chunk <= 0) chunk = default_chunk(f, rp(rows) - rp(0));
   chunk = std::max(kStage, (chunk / kStage) * kStage);
 
   std::vector<int> item_row, item_len, item_slot, item_rowlen;

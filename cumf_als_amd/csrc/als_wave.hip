@@ -429,8 +429,13 @@ __device__ __forceinline__ void wave_tiles_to_global(const f32x4 (&acc)[NB * (NB
       float v = acc[t][r];
       if (i < f && j < f) {
         if (i == j) v += reg;
-        tt[(size_t)i * f + j] = (T)v;  // T = _Float16: fp16 Gram storage (als.cu:335-441), round to nearest even
-        if (I != J) tt[(size_t)j * f + i] = (T)v;
+        // both triangles from ONE accumulator entry (als.h:39-143 writes tt[i][j] and tt[j][i] from the same
+        // temp): inside a diagonal tile the split products reach (i, j) and (j, i) in different orders, so
+        // only the upper entry is used there
+        if (I != J || i <= j) {
+          tt[(size_t)i * f + j] = (T)v;  // T = _Float16: fp16 Gram storage (als.cu:335-441), round to nearest even
+          if (i != j) tt[(size_t)j * f + i] = (T)v;
+        }
       } else if (i < f && j == f && rhs != nullptr) {
         rhs[i] = v;
       }

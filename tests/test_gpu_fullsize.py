@@ -1,0 +1,125 @@
+"""Parity at BASELINE.json's full size (Netflix shape: 480 189 x 17 770, 99 M ratings, f = 100) through
+properties that need no oracle run: every check below is an identity of the reference's arithmetic
+(als.cu:443-569 get_hermitian100, als.cu:750-757 RHS, als.cu:58-189 batched LU) that holds at any size.
+
+  * normal equations: for sampled rows u, the returned x_u satisfies (sum theta theta^T + lambda n_u I) x_u
+    = sum r theta, with the system rebuilt in fp64 by torch from the raw CSR -- LU and CG(6);
+  * checksum of checksums: the materialised Gram / RHS of ALL 17 770 Theta rows summed over the rows equals
+    sum_u n_u-weighted outer sums computed from the CSR side in fp64 -- every rating counted once;
+  * invariance to X_BATCH / THETA_BATCH (als.cu:768-777) and run-to-run determinism, bit for bit;
+  * the train RMSE of the iteration decreases.
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+pytestmark = pytest.mark.gpu
+
+F, LAM = 100, 0.048
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU (the product has no CPU fallback)")
+
+
+@pytest.fixture(scope="module")
+def netflix():
+    _need_gpu()
+    from cumf_als_amd import datagen
+
+    shp = datagen.SHAPES["netflix"]
+    r = datagen.synth_ratings(shp["m"], shp["n"], shp["nnz"], shp["nnz_test"], seed=0, device="cuda")
+    theta0 = (0.2 * np.random.RandomState(0).random_sample((r.n, F))).astype(np.float32)
+    return r, theta0
+
+
+def _residuals(indptr, indices, data, gather, x, rows, lam):
+    """max over the sampled rows of ||A x - b||_inf / ||b||_inf with A, b rebuilt in fp64."""
+    worst = 0.0
+    ip = indptr.cpu().numpy()
+    g64 = gather.double()
+    for u in rows:
+        s, e = int(ip[u]), int(ip[u + 1])
+        th = g64[indices[s:e].long()]
+        rv = data[s:e].double()
+        A = th.T @ th + lam * (e - s) * torch.eye(th.shape[1], dtype=torch.float64, device=th.device)
+        b = th.T @ rv
+        res = (A @ x[u].double() - b).abs().max() / b.abs().max()
+        worst = max(worst, float(res))
+    return worst
+
+
+@pytest.mark.parametrize("solver,tol", [("lu", 1e-4), ("cg", 5e-2)])
+def test_normal_equations_hold_at_full_size(alslib, netflix, solver, tol):
+    from cumf_als_amd import als
+
+    r, theta0 = netflix
+    eng = als.ALSEngine(r, F, LAM, solver=solver)
+    eng.init_factors(theta0)
+    eng.update_x()
+    eng.update_theta()
+    eng.update_x()  # CG: warm-started from a converged neighbourhood (cg.cu:48)
+    torch.cuda.synchronize()
+    rng = np.random.RandomState(1)
+    lens = np.diff(r.csr_indptr.cpu().numpy())
+    rows = np.concatenate([rng.choice(r.m, 400, replace=False), np.argsort(lens)[-3:], np.argsort(lens)[:3]])
+    wx = _residuals(r.csr_indptr, r.csr_indices, r.csr_data, eng.thetaT, eng.XT, rows, LAM)
+    assert wx <= tol, wx
+    eng.update_theta()
+    torch.cuda.synchronize()
+    clens = np.diff(r.csc_indptr.cpu().numpy())
+    cols = np.concatenate([rng.choice(r.n, 40, replace=False), np.argsort(clens)[-2:], np.argsort(clens)[:2]])
+    wt = _residuals(r.csc_indptr, r.csc_indices, r.csc_data, eng.XT, eng.thetaT, cols, LAM)
+    assert wt <= tol, wt
+    assert torch.isfinite(eng.XT).all() and torch.isfinite(eng.thetaT).all()
+
+
+def test_gram_checksum_of_checksums(alslib, netflix):
+    """sum_v A_v = sum_u n_u x_u x_u^T + lambda nnz I and sum_v b_v = sum_u (sum_v r_uv) x_u: the Theta-side
+    Gram batch (17 770 systems, rows of up to 50 000 ratings, chunked) against the CSR side in fp64."""
+    from cumf_als_amd import als
+
+    r, _ = netflix
+    x = torch.from_numpy((0.3 * np.random.RandomState(2).random_sample((r.m, F)) - 0.1).astype(np.float32)).cuda()
+    plan = als.Plan(r.csc_indptr.cpu().numpy(), F)
+    tt, rhs = als.get_hermitian(plan, r.csc_indices, r.csc_data, x, LAM)
+    torch.cuda.synchronize()
+    ip = r.csr_indptr.long()
+    n_u = (ip[1:] - ip[:-1]).double()
+    x64 = x.double()
+    want_A = (x64 * n_u[:, None]).T @ x64 + LAM * r.nnz * torch.eye(F, dtype=torch.float64, device="cuda")
+    rowsum = torch.zeros(r.m, dtype=torch.float64, device="cuda")
+    rows = torch.repeat_interleave(torch.arange(r.m, device="cuda"), (ip[1:] - ip[:-1]))
+    rowsum.index_add_(0, rows, r.csr_data.double())
+    want_b = x64.T @ rowsum
+    got_A = tt.double().sum(0)
+    got_b = rhs.double().sum(0)
+    assert float((got_A - want_A).abs().max() / want_A.abs().max()) <= 2e-6
+    assert float((got_b - want_b).abs().max() / want_b.abs().max()) <= 2e-6
+    # symmetric, bit for bit (both triangles are written from the same accumulator)
+    assert torch.equal(tt, tt.transpose(1, 2))
+
+
+def test_batches_and_reruns_are_bit_identical(alslib, netflix):
+    from cumf_als_amd import als
+
+    r, theta0 = netflix
+
+    def run(xb, tb):
+        eng = als.ALSEngine(r, F, LAM, solver="lu", x_batch=xb, theta_batch=tb)
+        eng.init_factors(theta0)
+        eng.iterate(1)
+        tr0, _ = eng.rmse()
+        eng.iterate(1)
+        tr1, _ = eng.rmse()
+        torch.cuda.synchronize()
+        return eng.XT.clone(), eng.thetaT.clone(), tr0, tr1
+
+    x1, t1, a0, a1 = run(1, 1)
+    x2, t2, _, _ = run(1, 1)
+    assert torch.equal(x1, x2) and torch.equal(t1, t2)        # deterministic: fixed reduction orders everywhere
+    x3, t3, _, _ = run(3, 2)
+    assert torch.equal(x1, x3) and torch.equal(t1, t3)        # als.cu:768-777: batches change nothing
+    assert a1 < a0                                             # the iteration descends
