@@ -51,8 +51,9 @@ def _residuals(indptr, indices, data, gather, x, rows, lam):
     return worst
 
 
+@pytest.mark.parametrize("gram_mode", ["auto", "exact", "fast"], indirect=True)
 @pytest.mark.parametrize("solver,tol", [("lu", 1e-4), ("cg", 5e-2)])
-def test_normal_equations_hold_at_full_size(alslib, netflix, solver, tol):
+def test_normal_equations_hold_at_full_size(alslib, netflix, gram_mode, solver, tol):
     from cumf_als_amd import als
 
     r, theta0 = netflix
@@ -74,6 +75,8 @@ def test_normal_equations_hold_at_full_size(alslib, netflix, solver, tol):
     wt = _residuals(r.csc_indptr, r.csc_indices, r.csc_data, eng.XT, eng.thetaT, cols, LAM)
     assert wt <= tol, wt
     assert torch.isfinite(eng.XT).all() and torch.isfinite(eng.thetaT).all()
+    if gram_mode == "fast":
+        assert als.gram_fast_status() == 0
 
 
 def test_gram_checksum_of_checksums(alslib, netflix):
@@ -123,3 +126,36 @@ def test_batches_and_reruns_are_bit_identical(alslib, netflix):
     x3, t3, _, _ = run(3, 2)
     assert torch.equal(x1, x3) and torch.equal(t1, t3)        # als.cu:768-777: batches change nothing
     assert a1 < a0                                             # the iteration descends
+
+
+def test_hugewiki_slab_normal_equations(alslib):
+    """BASELINE.json configs[3] at the size one GPU holds in the 8-GPU run: a 1/8 row slab of the hugewiki
+    shape (6.26 M x 39 780, 388 M ratings, 62 ratings per row), `reduce` scheme of cumf_als_amd.dist (X slab
+    resident, Theta from the slab-local CSC through materialised Grams: hugewiki.cu:2436-2745), CG(6).
+    Sampled X rows and Theta rows must satisfy their fp64-rebuilt normal equations."""
+    _need_gpu()
+    from cumf_als_amd import datagen
+    from cumf_als_amd import dist as cdist
+
+    shp = datagen.SHAPES["hugewiki"]
+    m_slab, n, nnz = shp["m"] // 8, shp["n"], shp["nnz"] // 8
+    r = datagen.synth_ratings(m_slab, n, nnz, 4096, seed=1000, device="cuda", col_seed=0)
+    theta0 = (0.2 * np.random.RandomState(0).random_sample((n, F))).astype(np.float32)
+    xb = np.array([0, m_slab], dtype=np.int64)
+    eng = cdist.DistALS.from_local_slab(m_slab, n, xb, r.csr_indptr, r.csr_indices, r.csr_data, F, shp["lam"],
+                                        cdist.HipOps(torch.device("cuda")), solver="cg", cg_iters=6)
+    eng.init_factors(theta0)
+    eng.iterate(2)
+    eng.update_x()
+    torch.cuda.synchronize()
+    rng = np.random.RandomState(3)
+    lens = np.diff(r.csr_indptr.cpu().numpy())
+    rows = np.concatenate([rng.choice(m_slab, 300, replace=False), np.argsort(lens)[-2:], np.argsort(lens)[:2]])
+    wx = _residuals(r.csr_indptr, r.csr_indices, r.csr_data, eng.thetaT, eng.XT, rows, shp["lam"])
+    assert wx <= 5e-2, wx
+    eng.update_theta()
+    torch.cuda.synchronize()
+    cols = rng.choice(n, 12, replace=False)
+    wt = _residuals(r.csc_indptr, r.csc_indices, r.csc_data, eng.XT, eng.thetaT, cols, shp["lam"])
+    assert wt <= 5e-2, wt
+    assert torch.isfinite(eng.XT).all() and torch.isfinite(eng.thetaT).all()
