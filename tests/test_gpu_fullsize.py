@@ -159,3 +159,55 @@ def test_hugewiki_slab_normal_equations(alslib):
     wt = _residuals(r.csc_indptr, r.csc_indices, r.csc_data, eng.XT, eng.thetaT, cols, shp["lam"])
     assert wt <= 5e-2, wt
     assert torch.isfinite(eng.XT).all() and torch.isfinite(eng.thetaT).all()
+
+
+@pytest.mark.parametrize("solver", ["lu", "cg"])
+def test_ml10m_config_matches_oracle(oracle, alslib, solver):
+    """BASELINE.json configs[0] at full size (MovieLens-10M shape 71 567 x 65 133, 9 M ratings, f = 10,
+    X_BATCH = THETA_BATCH = 1): five doALS iterations against the CPU oracle on the same matrix and the
+    same initial factors -- RMSE log, and for LU the factors."""
+    _need_gpu()
+    from cumf_als_amd import als, datagen
+
+    shp = datagen.SHAPES["ml10m"]
+    m, n, f, lam, iters = shp["m"], shp["n"], 10, shp["lam"], 5
+    r = datagen.synth_ratings(m, n, shp["nnz"], shp["nnz_test"], seed=0)
+    d = r.numpy()
+    th0, x0 = oracle.init_factors(m, n, f)
+    th_o, x_o = th0.copy(), x0.copy()
+    rm_o, log_o = oracle.do_als(d, th_o, x_o, m, n, f, lam, iters, solver=solver)
+    th, x, rm, log = als.do_als(d["csr_indptr"], d["csr_indices"], d["csr_data"], d["csc_indices"], d["csc_indptr"],
+                                d["csc_data"], d["coo_row"], d["test_row"], d["test_col"], d["test_data"], m, n, f,
+                                r.nnz, r.nnz_test, lam, iters, 1, 1, 0, thetat_init=th0, xt_init=x0, return_log=True,
+                                solver=solver)
+    tol = 1e-4 if solver == "lu" else 1e-3
+    assert np.abs(log - log_o).max() <= tol, np.abs(log - log_o).max()
+    assert abs(rm - rm_o) <= tol
+    if solver == "lu":
+        assert np.abs(th - th_o).max() <= 1e-3 * np.abs(th_o).max()
+        assert np.abs(x - x_o).max() <= 1e-3 * np.abs(x_o).max()
+
+
+@pytest.mark.parametrize("f,solver,tol", [(64, "lu", 1e-4), (200, "cg", 5e-2), (200, "lu", 2e-4)])
+def test_normal_equations_other_configs(alslib, netflix, f, solver, tol):
+    """BASELINE.json configs[2] (Netflix f = 200, CG vs LU: the two-wave kernels, the tile-buffer LU) and
+    configs[4] (f = 64) at full size: sampled rows against their fp64-rebuilt normal equations."""
+    from cumf_als_amd import als
+
+    r, _ = netflix
+    theta0 = (0.2 * np.random.RandomState(0).random_sample((r.n, f))).astype(np.float32)
+    eng = als.ALSEngine(r, f, LAM, solver=solver)
+    eng.init_factors(theta0)
+    eng.iterate(1)
+    eng.update_x()
+    torch.cuda.synchronize()
+    rng = np.random.RandomState(4)
+    lens = np.diff(r.csr_indptr.cpu().numpy())
+    rows = np.concatenate([rng.choice(r.m, 100, replace=False), np.argsort(lens)[-2:], np.argsort(lens)[:2]])
+    assert _residuals(r.csr_indptr, r.csr_indices, r.csr_data, eng.thetaT, eng.XT, rows, LAM) <= tol
+    eng.update_theta()
+    torch.cuda.synchronize()
+    clens = np.diff(r.csc_indptr.cpu().numpy())
+    cols = np.concatenate([rng.choice(r.n, 20, replace=False), np.argsort(clens)[-2:], np.argsort(clens)[:2]])
+    assert _residuals(r.csc_indptr, r.csc_indices, r.csc_data, eng.XT, eng.thetaT, cols, LAM) <= tol
+    assert torch.isfinite(eng.XT).all() and torch.isfinite(eng.thetaT).all()
