@@ -284,6 +284,18 @@ def gram_fast_status() -> int:
     return int(flags.value)
 
 
+def check_gram_fast() -> None:
+    """In gram mode "fast": raise if a factor or a rating left the f16 range since the last check (the
+    affected rows are not finite); a no-op (no device wait) in every other mode."""
+    if _libmod.load().cumf_get_gram_mode() != GRAM_FAST:
+        return
+    flags = gram_fast_status()
+    if flags:
+        what = " and ".join(w for b, w in ((1, "a factor"), (2, "a rating")) if flags & b)
+        raise RuntimeError(f"gram mode 'fast': {what} beyond the f16 range of the pre-split operands "
+                           "(|value| >= 15.99): use the default gram mode")
+
+
 def set_kernel_timing(enable: bool) -> None:
     _libmod.check(_libmod.load().cumf_set_kernel_timing(int(bool(enable))), "cumf_set_kernel_timing")
 
@@ -378,3 +390,4 @@ class ALSEngine:
         for _ in range(iters):
             self.update_x()
             self.update_theta()
+        check_gram_fast()

@@ -106,6 +106,9 @@ class HipOps:
     def update_fused(self, plan, colidx, val, gather, update, lam, solver, cg_iters):
         self.als.update_fused(plan, colidx, val, gather, update, lam, solver, cg_iters)
 
+    def check(self) -> None:
+        self.als.check_gram_fast()
+
     def get_hermitian(self, plan, colidx, val, gather, lam, tt, rhs):
         self.als.get_hermitian(plan, colidx, val, gather, lam, tt, rhs)
 
@@ -556,3 +559,6 @@ class DistALS:
         for _ in range(iters):
             self.update_x()
             self.update_theta()
+        check = getattr(self.ops, "check", None)  # gram mode "fast": range report of the HIP ops
+        if check is not None:
+            check()

@@ -147,6 +147,14 @@ def test_fast_gram_range_flags(alslib):
         als.update_fused(plan, rg.csr_indices, vals, torch.from_numpy(theta).cuda(), x, 0.05, "lu", 6)
         assert als.gram_fast_status() & 2
         assert als.gram_fast_status() == 0  # reading clears
+        # the engine raises instead of returning non-finite factors
+        import dataclasses
+
+        bad = dataclasses.replace(rg, csr_data=vals)
+        eng = als.ALSEngine(bad, f, 0.05, solver="lu")
+        eng.init_factors(theta)
+        with pytest.raises(RuntimeError, match="f16 range"):
+            eng.iterate(1)
     finally:
         als.set_gram_mode("auto")
 
