@@ -391,6 +391,33 @@ def main() -> int:
                     "matrix_pipe_frac_issued": float(nnz) * issued / (ms * 1e-3) / 1e12 / pipe_peak}
 
         xs, ts = sum(x_ms) / len(x_ms), sum(t_ms) / len(t_ms)
+        # the Gram pass alone (north_star: ">= 70 % of the HBM roofline on get_hermitian"): the same launches
+        # with the in-kernel solve switched off (ablation switch 1: the factors are wrong from here on, so this
+        # is the last use of the engine's state before it is re-initialised for the RMSE below)
+        gram_only = None
+        if wave and nb <= 7:  # (the two-wave kernels of f >= 112 have no such switch)
+            keep_x, keep_t = eng.XT.clone(), eng.thetaT.clone()
+            als.set_debug_switches(1)
+            als.set_kernel_timing(True)
+            g_ms = []
+            for _ in range(3):
+                eng.update_x()
+                gx = als.last_kernel_ms()[0]
+                eng.XT.copy_(keep_x)   # both passes gather REAL factors: the matrix pipe's clock depends on the data
+                eng.update_theta()     # (all-NaN tables run 15 % faster: power)
+                g_ms.append((gx, als.last_kernel_ms()[0]))
+                eng.thetaT.copy_(keep_t)
+            als.set_kernel_timing(False)
+            als.set_debug_switches(0)
+            gx = sum(v[0] for v in g_ms[1:]) / len(g_ms[1:])
+            gt = sum(v[1] for v in g_ms[1:]) / len(g_ms[1:])
+            gb_x = 4.0 * f * nnz + 8.0 * nnz + 4.0 * (m + 1)   # Gram + RHS inputs only (no factor write)
+            gb_t = 4.0 * f * nnz + 8.0 * nnz + 4.0 * (n + 1)
+            gram_only = {"x_side_ms": gx, "theta_side_ms": gt,
+                         "x_side_frac_of_hbm_roof": gb_x / (gx * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "theta_side_frac_of_hbm_roof": gb_t / (gt * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "note": "same kernel with the solve switched off (cumf_set_debug_switches(1)); the Theta "
+                                 "side gathers a 7 MB table from L2, so its fraction is bytes-equivalent, not HBM traffic"}
         out["dtype"] = ("f32" if not wave else
                         "f32 (opt-in fast mode: pre-split f16x2 operands, 3 products, 22-bit significand, fp32 accumulate)"
                         if mode == "fast" else "f32 (bf16x3-split products on the bf16 matrix pipe, fp32 accumulate)")
@@ -403,6 +430,7 @@ def main() -> int:
             "x_side": side(xs, bx, "x_side"), "theta_side": side(ts, bt, "theta_side"),
             "reduce_kernel_ms_x_side": sum(red_ms[0::2]) / len(red_ms[0::2]),
             "gram_mode": mode,
+            "gram_pass_alone": gram_only,
             "gram_flops_per_launch": float(nnz) * f * (f + 1),
             "gram_tflops": float(nnz) * f * (f + 1) / (avg_ms * 1e-3) / 1e12,
             # the matrix pipe next to the HBM roof: flops issued (tile padding and, on the split path,

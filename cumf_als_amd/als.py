@@ -296,6 +296,12 @@ def check_gram_fast() -> None:
                            "(|value| >= 15.99): use the default gram mode")
 
 
+def set_debug_switches(switches: int) -> None:
+    """Ablation switches for profiling (cumf_set_debug_switches): anything but 0 makes the results wrong on
+    purpose (1 = no solve: the Gram pass alone)."""
+    _libmod.check(_libmod.load().cumf_set_debug_switches(int(switches)), "cumf_set_debug_switches")
+
+
 def set_kernel_timing(enable: bool) -> None:
     _libmod.check(_libmod.load().cumf_set_kernel_timing(int(bool(enable))), "cumf_set_kernel_timing")
 

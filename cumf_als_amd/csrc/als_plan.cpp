@@ -279,6 +279,15 @@ int plan_lists(const cumf_plan_t* cp, PlanLists* out, bool need_tiles = true) {
   return 0;
 }
 
+// Ablation switches of the kernels (CUMF_ALS_DBG / cumf_set_debug_switches; 0 in production: any other
+// value makes the results wrong on purpose -- 1 = no solve, 2 = no Gram pass, 8 = every gather hits row 0,
+// 16 = no gather DMA).  bench.py uses 1 to time the Gram pass alone for the roofline of the Gram kernel.
+int g_debug_switches = -1;
+int debug_switches() {
+  if (g_debug_switches < 0) g_debug_switches = getenv("CUMF_ALS_DBG") ? atoi(getenv("CUMF_ALS_DBG")) : 0;
+  return g_debug_switches;
+}
+
 KernelArgs base_args(const cumf_plan_t* p, const int* colidx, const float* val, const float* gather, int f,
                      float lambda) {
   KernelArgs a{};
@@ -298,8 +307,7 @@ KernelArgs base_args(const cumf_plan_t* p, const int* colidx, const float* val, 
   a.row_begin = p->row_begin;
   a.f = f;
   a.lambda = lambda;
-  static const int dbg = getenv("CUMF_ALS_DBG") ? atoi(getenv("CUMF_ALS_DBG")) : 0;
-  a.dbg = dbg;
+  a.dbg = debug_switches();
   return a;
 }
 
@@ -500,6 +508,12 @@ extern "C" int cumf_set_gram_mode(int mode) {
   return 0;
 }
 extern "C" int cumf_get_gram_mode(void) { return gram_mode(); }
+
+extern "C" int cumf_set_debug_switches(int switches) {
+  if (switches < 0) return (int)hipErrorInvalidValue;
+  g_debug_switches = switches;
+  return 0;
+}
 
 extern "C" int cumf_set_kernel_timing(int enable) {
   set_kernel_timing(enable != 0);

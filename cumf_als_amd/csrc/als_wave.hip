@@ -1207,6 +1207,18 @@ __global__ __launch_bounds__(64, NB >= 10 ? 1 : 2) void als_wave_solve_kernel(co
   }
 }
 
+// This file is compiled twice per NB <= 7 (Makefile): part 0 holds everything but the LU form of
+// als_wave_kernel, part 1 only that (wave_lu_launch), built with -mllvm -enable-misched=false: the pre-RA
+// machine scheduler triples the accumulator spills at the Gram -> LU hand-over of that kernel (125 vs 38
+// registers; Netflix f = 100 LU 18.4 -> 18.0 ms on the same box) while every other kernel is faster with it
+// (f = 100 CG 16.6 vs 18.4, f = 200 CG 67 vs 82).
+#ifndef CUMF_WAVE_PART
+#define CUMF_WAVE_PART 0
+#endif
+template <int NB>
+hipError_t wave_lu_launch(const KernelArgs& a, long n_items, hipStream_t stream);
+
+#if CUMF_WAVE_PART == 0
 template <int NB>
 hipError_t wave_solve_launch(const KernelArgs& a, int mode, long n_rows, hipStream_t stream);
 template <>
@@ -1230,6 +1242,41 @@ hipError_t wave_solve_launch<CUMF_WAVE_NB>(const KernelArgs& a, int mode, long n
   return hipGetLastError();
 }
 
+#endif  // CUMF_WAVE_PART == 0
+
+#ifndef CUMF_WAVE_VARIANT
+#define CUMF_WAVE_VARIANT 0  // experiment switches (tools/wave_variants.sh)
+#endif
+
+#if CUMF_WAVE_PART == 1 && CUMF_WAVE_NB <= 7
+// ---- part 1: the LU form of the wave-per-item kernel
+template <int NB, int FC, int ARITH>
+static hipError_t launch_wave_lu(const KernelArgs& a, long n_items, hipStream_t stream) {
+  const size_t stage_lds = wave_stage_lds_floats<NB>() * sizeof(float);
+  const size_t lu_lds = wave_lu_lds_floats<NB>(a.f) * sizeof(float);
+  const size_t lds = lu_lds > stage_lds ? lu_lds : stage_lds;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(als_wave_kernel<NB, kModeLU, FC, ARITH>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL((als_wave_kernel<NB, kModeLU, FC, ARITH>), dim3((unsigned)n_items), dim3(64), lds, stream, a);
+  return hipGetLastError();
+}
+template <>
+hipError_t wave_lu_launch<CUMF_WAVE_NB>(const KernelArgs& a, long n_items, hipStream_t stream) {
+#if CUMF_WAVE_NB == 7 && !(CUMF_WAVE_VARIANT & 2)
+  // the reference's own specialisation: get_hermitian100 for f == 100 (als.cu:788-817)
+  if (a.f == 100)
+    return a.fast_words ? launch_wave_lu<7, 100, kArithFast>(a, n_items, stream)
+                        : launch_wave_lu<7, 100, kArithSplit3>(a, n_items, stream);
+#endif
+  return a.fast_words ? launch_wave_lu<CUMF_WAVE_NB, 0, kArithFast>(a, n_items, stream)
+                      : launch_wave_lu<CUMF_WAVE_NB, 0, kArithSplit3>(a, n_items, stream);
+}
+#endif
+
+#if CUMF_WAVE_PART == 0
 // ----------------------------------------------------------------------------------
 // Launcher (called by launch_half_iteration, als_kernels.hip)
 // ----------------------------------------------------------------------------------
@@ -1243,21 +1290,10 @@ static hipError_t launch_wave_fc(const KernelArgs& a, int mode, long n_items, hi
   } else if (mode == kModeCG) {
     hipLaunchKernelGGL((als_wave_kernel<NB, kModeCG, FC, ARITH>), dim3((unsigned)n_items), dim3(64), stage_lds, stream, a);
   } else {
-    const size_t lu_lds = wave_lu_lds_floats<NB>(a.f) * sizeof(float);
-    const size_t lds = lu_lds > stage_lds ? lu_lds : stage_lds;
-    if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(als_wave_kernel<NB, kModeLU, FC, ARITH>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL((als_wave_kernel<NB, kModeLU, FC, ARITH>), dim3((unsigned)n_items), dim3(64), lds, stream, a);
+    return wave_lu_launch<NB>(a, n_items, stream);  // part 1 of this file (picks FC and the arithmetic itself)
   }
   return hipGetLastError();
 }
-
-#ifndef CUMF_WAVE_VARIANT
-#define CUMF_WAVE_VARIANT 0  // experiment switches (tools/wave_variants.sh)
-#endif
 
 template <int NB>
 hipError_t wave_item_launch(const KernelArgs& a, int mode, long n_items, hipStream_t stream);
@@ -1297,5 +1333,7 @@ hipError_t wave_item_launch<CUMF_WAVE_NB>(const KernelArgs& a, int mode, long n_
                       : launch_wave_fc<CUMF_WAVE_NB, 0, kArithSplit3>(a, mode, n_items, stream);
 #endif
 }
+
+#endif  // CUMF_WAVE_PART == 0
 
 }  // namespace cumf

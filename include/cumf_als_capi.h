@@ -185,6 +185,10 @@ int cumf_get_gram_mode(void);
  * for the last half-iteration and returns their durations in milliseconds.
  */
 int cumf_set_kernel_timing(int enable);
+/* Ablation switches of the half-iteration kernels for profiling (also CUMF_ALS_DBG): 0 = production; any
+ * other value makes the RESULTS WRONG on purpose: 1 = no solve (the Gram pass alone), 2 = no Gram pass,
+ * 8 = every gather hits row 0, 16 = no gather DMA.  bench.py times the Gram pass alone with 1. */
+int cumf_set_debug_switches(int switches);
 int cumf_last_kernel_ms(float* item_kernel_ms, float* reduce_kernel_ms);
 
 /* Library/version probe used by the loaders' "fail loudly" checks. */
