@@ -966,15 +966,8 @@ __global__ __launch_bounds__(64, CUMF_WAVE_MIN_WAVES) void als_wave_kernel(const
   const int slot = a.dense_slots ? item : a.item_slot[item];
   const int rowlen = a.item_rowlen[item];
   const int f = FC ? FC : a.f;
-  // Two waves share a SIMD.  Left alone they fall into lockstep (both in their MFMA phase, then both
-  // in their split phase: matrix pipe and VALU port each idle half of the time).  A static priority for
-  // the wave in the odd hardware slot breaks the symmetry: it runs at single-wave speed and the
-  // other one fills the matrix pipe whenever the first is splitting (MI355X_MICROARCH.md, "Two waves
-  // per SIMD", item 4).  a.dbg & 4 turns it off (ablation).
-  if (!(a.dbg & 4)) {
-    const unsigned wave_slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);  // HW_REG_HW_ID.WAVE_ID
-    if (wave_slot & 1) __builtin_amdgcn_s_setprio(1);
-  }
+  // (A static s_setprio for the wave in the odd hardware slot, meant to break a lockstep of the two waves
+  // of a SIMD, measured neutral to slightly negative -- X side 6.70 vs 6.57 ms without it -- and is gone.)
 
   f32x4 acc[NT];
 #pragma unroll
