@@ -397,18 +397,22 @@ def main() -> int:
         gram_only = None
         if wave and nb <= 7:  # (the two-wave kernels of f >= 112 have no such switch)
             keep_x, keep_t = eng.XT.clone(), eng.thetaT.clone()
-            als.set_debug_switches(1)
-            als.set_kernel_timing(True)
             g_ms = []
-            for _ in range(3):
-                eng.update_x()
-                gx = als.last_kernel_ms()[0]
-                eng.XT.copy_(keep_x)   # both passes gather REAL factors: the matrix pipe's clock depends on the data
-                eng.update_theta()     # (all-NaN tables run 15 % faster: power)
-                g_ms.append((gx, als.last_kernel_ms()[0]))
+            try:
+                als.set_debug_switches(1)
+                als.set_kernel_timing(True)
+                for _ in range(3):
+                    eng.update_x()
+                    gx = als.last_kernel_ms()[0]
+                    eng.XT.copy_(keep_x)   # both passes gather REAL factors: the matrix pipe's clock depends on the data
+                    eng.update_theta()     # (all-NaN tables run 15 % faster: power)
+                    g_ms.append((gx, als.last_kernel_ms()[0]))
+                    eng.thetaT.copy_(keep_t)
+            finally:
+                als.set_kernel_timing(False)
+                als.set_debug_switches(0)
+                eng.XT.copy_(keep_x)
                 eng.thetaT.copy_(keep_t)
-            als.set_kernel_timing(False)
-            als.set_debug_switches(0)
             gx = sum(v[0] for v in g_ms[1:]) / len(g_ms[1:])
             gt = sum(v[1] for v in g_ms[1:]) / len(g_ms[1:])
             gb_x = 4.0 * f * nnz + 8.0 * nnz + 4.0 * (m + 1)   # Gram + RHS inputs only (no factor write)
