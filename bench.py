@@ -211,6 +211,8 @@ def main() -> int:
     ap.add_argument("--cg-iters", type=int, default=6)
     ap.add_argument("--scheme", default="gather", choices=["gather", "reduce"])
     ap.add_argument("--no-fast-leg", action="store_true", help="skip the informational opt-in fast-mode leg")
+    ap.add_argument("--no-gram-leg", action="store_true",
+                    help="skip the Gram-pass-alone leg (profiling runs: its solve-less launches would skew per-kernel averages)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
     a = ap.parse_args()
@@ -395,7 +397,7 @@ def main() -> int:
         # with the in-kernel solve switched off (ablation switch 1: the factors are wrong from here on, so this
         # is the last use of the engine's state before it is re-initialised for the RMSE below)
         gram_only = None
-        if wave and nb <= 7:  # (the two-wave kernels of f >= 112 have no such switch)
+        if wave and nb <= 7 and not a.no_gram_leg:  # (the two-wave kernels of f >= 112 have no such switch)
             keep_x, keep_t = eng.XT.clone(), eng.thetaT.clone()
             g_ms = []
             try:

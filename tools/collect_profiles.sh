@@ -13,7 +13,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_${ROUND:-r02}/${TAG:-lu}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps ${STEPS:-3} --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-}"
+BENCH="python $R/bench.py --steps ${STEPS:-3} --warmup 1 --no-cpu-baseline --no-gram-leg --no-fast-leg ${BENCH_ARGS:-}"
 rm -rf /tmp/prof_kt /tmp/prof_sq /tmp/prof_f /tmp/prof_w /tmp/prof_t
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -o kt -- $BENCH > $OUT/bench_under_kernel_trace.json 2> $OUT/kt.err
 python - <<PY > $OUT/kernel_stats.csv
