@@ -10,12 +10,18 @@ Netflix shape (17770 x 480189, 99 072 112 ratings), f = 100, lambda = 0.048, LU 
 
 Printed JSON (one line, rank 0):
   value       2 * nnz * K / t           ratings/s per half-iteration, whole job
-  roofline    dominant kernel = the per-item Gram(+solve) kernel `als_item_kernel`;
-              achieved = algorithmic bytes of a half-iteration (SURVEY.md 8d:
-              4 f nnz + 8 nnz + 4 (rows+1) + 4 f rows) / its HIP-event duration, averaged
-              over the X-side and Theta-side launches of the timed steps; peak = 8 TB/s HBM.
+  roofline    dominant kernel = the per-item Gram(+solve) kernel (its name is read back from the
+              library: the symbol that was dispatched); achieved = algorithmic bytes of a
+              half-iteration (4 f nnz + 8 nnz + 4 (rows+1) + 4 f rows) / its HIP-event
+              duration, averaged over the X-side and Theta-side launches; peak = 8 TB/s HBM.  Emitted
+              for every --f, --solver and for --shape hugewiki (per-GPU slab).  `traffic` is replayed
+              from the committed rocprofv3 --pmc passes (profiles/traffic.json), and only when that file
+              was collected for the kernel that was dispatched here.
   cpu_baseline  the CPU oracle (oracle/, "port": the reference has no CPU path) timed on
               this host's cores on a row sample of the same matrix, N = 1 only.
+
+N > 1 on a box with fewer GPUs than ranks (tests): CUMF_BENCH_BACKEND=gloo stands in for RCCL (collectives
+staged through the host) and ranks share devices (local_rank % device_count).
 """
 from __future__ import annotations
 
@@ -139,27 +145,39 @@ def parity_at_scale(r, f, lam, solver, cg_iters, oracle_out, dev):
     return out
 
 
-def measured_traffic():
+def measured_traffic(kernel: str):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (tools/collect_profiles.sh -> profiles/): (2 * FETCH_SIZE + WRITE_SIZE) KiB, FETCH_SIZE
-    doubled as MI355X_MICROARCH.md prescribes for gfx950.  None when no profile is committed."""
+    (tools/collect_profiles.sh -> profiles/traffic.json): (2 * FETCH_SIZE + WRITE_SIZE) KiB, FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for gfx950.  The file is keyed by the kernel name rocprofv3
+    printed; returns (entry or None, note): a profile of ANOTHER kernel is never replayed."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as fh:
-            return json.load(fh)
+            table = json.load(fh)
     except (OSError, ValueError):
-        return None
+        return None, "profiles/traffic.json is missing"
+    for ent in table.get("kernels", []):
+        if ent.get("kernel", "").replace(" ", "") == kernel.replace(" ", ""):
+            return ent, None
+    have = [e.get("kernel") for e in table.get("kernels", [])]
+    return None, f"profiles/traffic.json holds no PMC pass for the dispatched kernel {kernel!r} (it has {have})"
 
 
-def fast_leg(r, f, lam, a, theta0, eng_default):
-    """Informational, outside the timed region of `value`: the same steps in the OPT-IN gram mode "fast"
-    (pre-split f16x2 operands, 3 MFMA products per fp32 product, 22 significand bits),
-    plus the distance of one X and one Theta half-iteration from the default arithmetic on the same inputs."""
+def mode_leg(mode, r, f, lam, a, theta0, eng_default):
+    """Informational, outside the timed region of `value`: the same steps in another gram mode -- "fast", the
+    OPT-IN 22-bit arithmetic (pre-split f16x2 operands, 3 MFMA products per fp32 product), or
+    "exact", the reference's own arithmetic (fp32 MFMA = the k-ordered fmaf chain of als.h:39-143, bit-exact
+    Gram) -- plus the distance of one X and one Theta half-iteration from the default arithmetic on the same
+    inputs."""
+    return fast_leg(r, f, lam, a, theta0, eng_default, mode)
+
+
+def fast_leg(r, f, lam, a, theta0, eng_default, mode="fast"):
     import torch
 
     from cumf_als_amd import als
 
-    als.set_gram_mode("fast")
+    als.set_gram_mode(mode)
     try:
         eng = als.ALSEngine(r, f, lam, solver=a.solver, cg_iters=a.cg_iters)
         eng.init_factors(theta0)
@@ -173,7 +191,8 @@ def fast_leg(r, f, lam, a, theta0, eng_default):
             eng.update_theta()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / a.steps
-        flags = als.gram_fast_status()
+        flags = als.gram_fast_status() if mode == "fast" else 0
+        kernel = als.last_kernel_name()
         tr, te = eng.rmse()
         # same inputs, both arithmetics: the default engine's current factors
         eng.thetaT.copy_(eng_default.thetaT)
@@ -191,12 +210,33 @@ def fast_leg(r, f, lam, a, theta0, eng_default):
         eng_default.update_theta()
         dth = float((th_fast - eng_default.thetaT).abs().max() / eng_default.thetaT.abs().max())
         eng_default.thetaT.copy_(keep_t)
-        return {"opt_in": "CUMF_ALS_GRAM=fast / cumf_set_gram_mode(CUMF_GRAM_FAST)", "ms_per_step": 1e3 * dt,
-                "value": 2.0 * r.nnz / dt, "unit": "ratings/s", "range_flags": flags,
+        return {"opt_in": f"CUMF_ALS_GRAM={mode} / cumf_set_gram_mode(CUMF_GRAM_{mode.upper()})", "kernel": kernel,
+                "ms_per_step": 1e3 * dt, "value": 2.0 * r.nnz / dt, "unit": "ratings/s", "range_flags": flags,
                 "rmse": {"train": tr, "test": te, "after_iterations": max(1, a.warmup) + a.steps},
                 "x_half_iteration_max_rel_vs_default": dx, "theta_half_iteration_max_rel_vs_default": dth}
     finally:
         als.set_gram_mode("auto")
+
+
+def gram_pass_alone(a):
+    """The Gram pass alone (north_star: ">= 70 % of the HBM roofline on get_hermitian"): the same launches with
+    the in-kernel solve compiled to a switch -- that switch exists only in the profiling build
+    libALS_ablate.so, so the leg runs tools/gram_pass_alone.py in a process of its own with CUMF_ALS_LIB
+    pointing at it.  None when that library was not built."""
+    import subprocess
+
+    from cumf_als_amd import lib as _lib
+
+    if not os.path.exists(_lib.ABLATE_LIB_PATH):
+        return None
+    env = dict(os.environ, CUMF_ALS_LIB=_lib.ABLATE_LIB_PATH)
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "gram_pass_alone.py"), "--shape", a.shape, "--f", str(a.f),
+           "--solver", a.solver, "--seed", str(a.seed), "--scale", str(a.scale)]
+    try:
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as e:  # informational leg: never takes the bench line down
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def main() -> int:
@@ -210,7 +250,11 @@ def main() -> int:
     ap.add_argument("--solver", default="lu", choices=["lu", "cg"])
     ap.add_argument("--cg-iters", type=int, default=6)
     ap.add_argument("--scheme", default="gather", choices=["gather", "reduce"])
-    ap.add_argument("--no-fast-leg", action="store_true", help="skip the informational opt-in fast-mode leg")
+    ap.add_argument("--no-fast-leg", action="store_true",
+                    help="skip the informational legs in the other gram modes (opt-in fast, reference-exact)")
+    ap.add_argument("--allow-missing-traffic", action="store_true",
+                    help="headline workload only: print traffic: null instead of failing when profiles/traffic.json "
+                         "has no PMC pass of the dispatched kernel")
     ap.add_argument("--no-gram-leg", action="store_true",
                     help="skip the Gram-pass-alone leg (profiling runs: its solve-less launches would skew per-kernel averages)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -228,13 +272,18 @@ def main() -> int:
         raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    backend = os.environ.get("CUMF_BENCH_BACKEND", "nccl")  # "gloo": stand-in for RCCL when ranks share a GPU (tests)
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     shp = datagen.SHAPES[a.shape]
     s = a.scale
@@ -261,6 +310,7 @@ def main() -> int:
     theta0 = (0.2 * torch.rand((n, f), generator=g, dtype=torch.float32)).numpy()
 
     item_ms = []
+    kernels = {}
     if slab_mode:
         from cumf_als_amd import dist as cdist
 
@@ -273,9 +323,11 @@ def main() -> int:
             eng.update_x()
             if timed:
                 item_ms.append(als.last_kernel_ms())
+                kernels["x"] = als.last_kernel_name()
             eng.update_theta()
             if timed:
                 item_ms.append(als.last_kernel_ms())
+                kernels["theta"] = als.last_kernel_name()
 
         def barrier():
             torch.cuda.synchronize()
@@ -292,9 +344,11 @@ def main() -> int:
             eng.update_x()
             if timed:
                 item_ms.append(als.last_kernel_ms())
+                kernels["x"] = als.last_kernel_name()
             eng.update_theta()
             if timed:
                 item_ms.append(als.last_kernel_ms())
+                kernels["theta"] = als.last_kernel_name()
 
         def barrier():
             torch.cuda.synchronize()
@@ -334,7 +388,7 @@ def main() -> int:
     if world > 1:
         import torch.distributed as dist
 
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -355,7 +409,7 @@ def main() -> int:
                        "step": "update-X + update-Theta (two half-iterations)", "gen_seconds": round(t_gen, 2)},
         }
 
-    if world == 1 and not slab_mode:
+    if world == 1:
         # roofline leg: the same steps again with HIP events around each kernel launch
         als.set_kernel_timing(True)
         for _ in range(max(2, min(a.steps, 5))):
@@ -366,93 +420,84 @@ def main() -> int:
         t_ms = [v[0] for v in item_ms[1::2]]
         red_ms = [v[1] for v in item_ms]
         cg = a.solver == "cg"
-        bx, bt = alg_bytes(nnz, m, f, cg), alg_bytes(nnz, n, f, cg)
+        # rows of each side as this GPU sees them (slab mode: its X slab; the Theta side forms PARTIAL Grams of all
+        # n columns over the slab's ratings and writes packed Grams instead of factors -- bytes_theta below)
+        rows_x = r.m
+        bx = alg_bytes(r.nnz, rows_x, f, cg)
+        if slab_mode:
+            bt = 4.0 * f * r.nnz + 8.0 * r.nnz + 4.0 * (n + 1) + 4.0 * n * (f * (f + 1) // 2 + f)
+        else:
+            bt = alg_bytes(r.nnz, n, f, cg)
         avg_ms = (sum(x_ms) + sum(t_ms)) / (len(x_ms) + len(t_ms))
         avg_bytes = 0.5 * (bx + bt)
         achieved = avg_bytes / (avg_ms * 1e-3) / 1e9
         mode = als.get_gram_mode()
         nb = f // 16 + 1
-        wave = mode in ("auto", "fast") and 2 <= nb <= 13
-        sv = "CG" if cg else "LU"
-        kernel = ((f"cumf::als_wave_kernel<{nb}, {sv}, {100 if f == 100 else 0}>" if nb <= 7
-                   else f"cumf::als_wave_multi_kernel<{nb}, 2, {sv}>") if wave
-                  else f"cumf::als_item_kernel<{nb}, float4, {sv}>")
-        traffic = measured_traffic() or {}
+        kernel = kernels.get("x") or als.last_kernel_name()
+        wave = "als_wave" in kernel
+        traffic, traffic_note = measured_traffic(kernel)
+        headline = a.shape == "netflix" and f == 100 and a.solver == "lu" and a.scale == 1.0 and mode == "auto"
+        if traffic is None and headline and not a.allow_missing_traffic:
+            raise SystemExit("bench.py: " + traffic_note + "; re-collect with tools/collect_profiles.sh (or pass "
+                             "--allow-missing-traffic to print traffic: null)")
+        traffic = traffic or {}
         # matrix-pipe work ISSUED per rating: upper-triangular 16x16 tiles x 2*16*16 flops, x6 bf16
         # products on the split path (als_wave.hip), x3 f16 products in the opt-in fast mode, x1 on the
         # fp32 MFMA path
         products = (3 if mode == "fast" else 6) if wave else 1
         issued = nb * (nb + 1) / 2 * 512.0 * products
         pipe_peak = 2500.0 if wave else MFMA_F32_PEAK_TFLOPS
+        nnz_gpu = r.nnz
 
-        def side(ms, nbytes, key):
+        def side(ms, nbytes, key, name):
             ach = nbytes / (ms * 1e-3) / 1e9
-            return {"ms": ms, "alg_bytes": nbytes, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
+            return {"kernel": name, "ms": ms, "alg_bytes": nbytes, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
                     "traffic": (traffic.get(key) or {}).get("bytes_per_launch"),
-                    "gram_tflops_useful": float(nnz) * f * (f + 1) / (ms * 1e-3) / 1e12,
-                    "matrix_pipe_frac_issued": float(nnz) * issued / (ms * 1e-3) / 1e12 / pipe_peak}
+                    "gram_tflops_useful": float(nnz_gpu) * f * (f + 1) / (ms * 1e-3) / 1e12,
+                    "matrix_pipe_frac_issued": float(nnz_gpu) * issued / (ms * 1e-3) / 1e12 / pipe_peak}
 
         xs, ts = sum(x_ms) / len(x_ms), sum(t_ms) / len(t_ms)
-        # the Gram pass alone (north_star: ">= 70 % of the HBM roofline on get_hermitian"): the same launches
-        # with the in-kernel solve switched off (ablation switch 1: the factors are wrong from here on, so this
-        # is the last use of the engine's state before it is re-initialised for the RMSE below)
         gram_only = None
-        if wave and nb <= 7 and not a.no_gram_leg:  # (the two-wave kernels of f >= 112 have no such switch)
-            keep_x, keep_t = eng.XT.clone(), eng.thetaT.clone()
-            g_ms = []
-            try:
-                als.set_debug_switches(1)
-                als.set_kernel_timing(True)
-                for _ in range(3):
-                    eng.update_x()
-                    gx = als.last_kernel_ms()[0]
-                    eng.XT.copy_(keep_x)   # both passes gather REAL factors: the matrix pipe's clock depends on the data
-                    eng.update_theta()     # (all-NaN tables run 15 % faster: power)
-                    g_ms.append((gx, als.last_kernel_ms()[0]))
-                    eng.thetaT.copy_(keep_t)
-            finally:
-                als.set_kernel_timing(False)
-                als.set_debug_switches(0)
-                eng.XT.copy_(keep_x)
-                eng.thetaT.copy_(keep_t)
-            gx = sum(v[0] for v in g_ms[1:]) / len(g_ms[1:])
-            gt = sum(v[1] for v in g_ms[1:]) / len(g_ms[1:])
-            gb_x = 4.0 * f * nnz + 8.0 * nnz + 4.0 * (m + 1)   # Gram + RHS inputs only (no factor write)
-            gb_t = 4.0 * f * nnz + 8.0 * nnz + 4.0 * (n + 1)
-            gram_only = {"x_side_ms": gx, "theta_side_ms": gt,
-                         "x_side_frac_of_hbm_roof": gb_x / (gx * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "theta_side_frac_of_hbm_roof": gb_t / (gt * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "note": "same kernel with the solve switched off (cumf_set_debug_switches(1)); the Theta "
-                                 "side gathers a 7 MB table from L2, so its fraction is bytes-equivalent, not HBM traffic"}
+        if wave and not slab_mode and not a.no_gram_leg:
+            gram_only = gram_pass_alone(a)
         out["dtype"] = ("f32" if not wave else
                         "f32 (opt-in fast mode: pre-split f16x2 operands, 3 products, 22-bit significand, fp32 accumulate)"
                         if mode == "fast" else "f32 (bf16x3-split products on the bf16 matrix pipe, fp32 accumulate)")
         out["roofline"] = {
             "bound": "hbm", "kernel": kernel,
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic.get("bytes_per_launch"), "traffic_source": traffic.get("source"),
+            "traffic": traffic.get("bytes_per_launch"), "traffic_source": traffic.get("source") or traffic_note,
             "alg_bytes_per_launch": avg_bytes, "avg_launch_ms": avg_ms,
             "x_side_ms": xs, "theta_side_ms": ts,
-            "x_side": side(xs, bx, "x_side"), "theta_side": side(ts, bt, "theta_side"),
+            "x_side": side(xs, bx, "x_side", kernels.get("x")),
+            "theta_side": side(ts, bt, "theta_side", kernels.get("theta")),
             "reduce_kernel_ms_x_side": sum(red_ms[0::2]) / len(red_ms[0::2]),
+            "reduce_kernel_ms_theta_side": sum(red_ms[1::2]) / len(red_ms[1::2]),
             "gram_mode": mode,
             "gram_pass_alone": gram_only,
-            "gram_flops_per_launch": float(nnz) * f * (f + 1),
-            "gram_tflops": float(nnz) * f * (f + 1) / (avg_ms * 1e-3) / 1e12,
+            "gram_flops_per_launch": float(nnz_gpu) * f * (f + 1),
+            "gram_tflops": float(nnz_gpu) * f * (f + 1) / (avg_ms * 1e-3) / 1e12,
             # the matrix pipe next to the HBM roof: flops issued (tile padding and, on the split path,
             # the six bf16 products per fp32 product included) against the pipe's dense peak
             "mfma": {"bound": "mfma", "pipe": (f"{'f16' if mode == 'fast' else 'bf16'} ({products} products per fp32 product)"
                                                 if wave else "fp32"),
-                     "achieved": float(nnz) * issued / (avg_ms * 1e-3) / 1e12, "peak": pipe_peak, "unit": "TFLOP/s",
-                     "frac": float(nnz) * issued / (avg_ms * 1e-3) / 1e12 / pipe_peak},
+                     "achieved": float(nnz_gpu) * issued / (avg_ms * 1e-3) / 1e12, "peak": pipe_peak, "unit": "TFLOP/s",
+                     "frac": float(nnz_gpu) * issued / (avg_ms * 1e-3) / 1e12 / pipe_peak},
             # what a perfect kernel of this design would take: the larger of the HBM time of the
             # algorithmic bytes and the matrix-pipe time of the issued flops
-            "floor_ms": {"hbm": avg_bytes / (HBM_PEAK_GBS * 1e9) * 1e3, "matrix_pipe": float(nnz) * issued / (pipe_peak * 1e12) * 1e3},
+            "floor_ms": {"hbm": avg_bytes / (HBM_PEAK_GBS * 1e9) * 1e3,
+                         "matrix_pipe": float(nnz_gpu) * issued / (pipe_peak * 1e12) * 1e3},
         }
+        if slab_mode:
+            out["roofline"]["note"] = ("per-GPU slab: the X side is the fused Gram+solve kernel over the slab's rows; the "
+                                       "Theta side is the partial-Gram kernel of all n columns over the slab's ratings "
+                                       "(packed Grams written, then reduce-scatter + solve + all-gather outside it)")
+    if world == 1 and not slab_mode:
         tr, te = eng.rmse()
         out["rmse"] = {"train": tr, "test": te, "after_iterations": a.warmup + a.steps + len(x_ms)}
         if mode == "auto" and wave and not a.no_fast_leg:
-            out["gram_fast_mode"] = fast_leg(r, f, lam, a, theta0, eng)
+            out["gram_fast_mode"] = mode_leg("fast", r, f, lam, a, theta0, eng)
+            out["gram_exact_mode"] = mode_leg("exact", r, f, lam, a, theta0, eng)
         if not a.no_cpu_baseline:
             d = {k: v for k, v in r.numpy().items() if k.startswith("cs")}
             oracle_out, out["cpu_baseline"] = cpu_baseline(d, f, lam, a.solver)

@@ -19,6 +19,7 @@ import numpy as np
 from . import lib as _libmod
 
 SOLVER_CG, SOLVER_LU = 0, 1
+CUMF_ERR_FAST_RANGE = 10001  # include/cumf_als_capi.h
 
 
 def _solver_id(solver) -> int:
@@ -38,7 +39,7 @@ def _hostptr(a: np.ndarray, dtype) -> C.c_void_p:
 def do_als(csrrow, csrcol, csrval, cscrow, csccol, cscval, coorow, coorowtest, coocoltest, coovaltest,
            m, n, f, nnz, nnz_test, lambda_, iters, xbatch, thetabatch, deviceid=0, *,
            thetat_init=None, xt_init=None, solver="cg", cg_iters=6, fused=True,
-           exact_test_grid=False, surpass_nan=False, quiet=True, return_log=False, tt_fp16=False):
+           exact_test_grid=False, surpass_nan=False, quiet=True, return_log=False, tt_fp16=None):
     """`DoAls` (als_tf.cc): run `iters` ALS iterations on device `deviceid`.
 
     Argument names follow the TF op's inputs: csrrow = CSR indptr (m+1), csrcol = CSR
@@ -47,7 +48,10 @@ def do_als(csrrow, csrcol, csrval, cscrow, csccol, cscval, coorow, coorowtest, c
 
     Initial factors default to the CLI's initialisation (main.cpp:72-78 evaluated with
     numpy's generator is NOT the same stream as libc rand(); pass `thetat_init` to
-    reproduce a particular start).
+    reproduce a particular start).  tt_fp16: True / False select the fp16 Gram storage of the CG solver
+    (CUMF_TT_FP16, als.cu:25-33) for this call; None (default) leaves the process-wide setting
+    (`cumf_set_tt_fp16` / environment CUMF_ALS_TT_FP16) alone.  Raises RuntimeError when the opt-in gram
+    mode "fast" meets data outside its range (the C entry point returns NaN and sets cumf_last_error).
     """
     lib = _libmod.load()
     if thetat_init is None:
@@ -73,12 +77,23 @@ def do_als(csrrow, csrcol, csrval, cscrow, csccol, cscval, coorow, coorowtest, c
         _hostptr(np.ascontiguousarray(coocoltest, np.int32), np.int32),
         _hostptr(np.ascontiguousarray(coovaltest, np.float32), np.float32),
     ]
-    lib.cumf_set_tt_fp16(int(bool(tt_fp16)))  # CUMF_TT_FP16 (als.cu:25-33): fp16 Gram storage for the CG solver
-    rmse = lib.cumf_doALS_ex(*args, int(m), int(n), int(f), int(nnz), int(nnz_test), float(lambda_),
-                             int(iters), int(xbatch), int(thetabatch), int(deviceid),
-                             _solver_id(solver), int(cg_iters), int(bool(fused)), int(bool(exact_test_grid)),
-                             int(bool(surpass_nan)), int(bool(quiet)), _hostptr(log, np.float32))
-    lib.cumf_set_tt_fp16(0)
+    prev_fp16 = lib.cumf_get_tt_fp16()  # (resolves the environment default on first use)
+    if tt_fp16 is not None:
+        lib.cumf_set_tt_fp16(int(bool(tt_fp16)))  # CUMF_TT_FP16 (als.cu:25-33): fp16 Gram storage for the CG solver
+    try:
+        lib.cumf_last_error()
+        rmse = lib.cumf_doALS_ex(*args, int(m), int(n), int(f), int(nnz), int(nnz_test), float(lambda_),
+                                 int(iters), int(xbatch), int(thetabatch), int(deviceid),
+                                 _solver_id(solver), int(cg_iters), int(bool(fused)), int(bool(exact_test_grid)),
+                                 int(bool(surpass_nan)), int(bool(quiet)), _hostptr(log, np.float32))
+        err = lib.cumf_last_error()
+    finally:
+        lib.cumf_set_tt_fp16(prev_fp16)
+    if err == CUMF_ERR_FAST_RANGE:
+        raise RuntimeError("gram mode 'fast': a factor or a rating beyond the f16 range of the pre-split operands "
+                           "(|value| >= 15.99): use the default gram mode")
+    if err:
+        raise RuntimeError(f"cumf_doALS_ex failed with error {err}")
     if return_log:
         return thetat, xt, float(rmse), log[:iters]
     return thetat, xt, float(rmse)
@@ -186,6 +201,25 @@ def get_hermitian(plan: Plan, colidx, val, gather, lambda_: float, tt=None, rhs=
                                          _dp(rhs, torch.float32), f, float(lambda_), _stream()),
                   "cumf_get_hermitian")
     return tt, rhs
+
+
+def get_hermitian_packed(plan: Plan, colidx, val, gather, lambda_: float, packed=None, rhs=None, want_rhs=True):
+    """The Gram batch of the plan's rows as packed upper triangles packed[rows, f(f+1)/2] (+ rhs[rows,f]),
+    written straight from the accumulators (cumf_get_hermitian_packed): the multi-GPU reduction payload."""
+    import torch
+
+    lib = _libmod.load()
+    f, rows = plan.f, plan.batch_rows
+    _libmod.check(lib.cumf_check_gather_table(gather.shape[0], f, SOLVER_LU, 1), "cumf_check_gather_table")
+    if packed is None:
+        packed = torch.empty((rows, f * (f + 1) // 2), dtype=torch.float32, device=gather.device)
+    if rhs is None and want_rhs:
+        rhs = torch.empty((rows, f), dtype=torch.float32, device=gather.device)
+    _libmod.check(lib.cumf_get_hermitian_packed(plan._h, _dp(colidx, torch.int32), _dp(val, torch.float32),
+                                                _dp(gather, torch.float32), _dp(packed, torch.float32),
+                                                _dp(rhs, torch.float32), f, float(lambda_), _stream()),
+                  "cumf_get_hermitian_packed")
+    return packed, rhs
 
 
 def cg_solve(A, x, b, cg_iters: int = 6):
@@ -297,9 +331,20 @@ def check_gram_fast() -> None:
 
 
 def set_debug_switches(switches: int) -> None:
-    """Ablation switches for profiling (cumf_set_debug_switches): anything but 0 makes the results wrong on
-    purpose (1 = no solve: the Gram pass alone)."""
-    _libmod.check(_libmod.load().cumf_set_debug_switches(int(switches)), "cumf_set_debug_switches")
+    """Ablation switches (1 = no solve: the Gram pass alone, ...; the results are wrong on purpose).  They
+    exist only in the profiling build libALS_ablate.so (`CUMF_ALS_LIB=.../libALS_ablate.so`, used by
+    tools/gram_pass_alone.py); the product library has no such entry point and this raises."""
+    lib = _libmod.load()
+    if not hasattr(lib, "cumf_set_debug_switches"):
+        raise RuntimeError("ablation switches exist only in libALS_ablate.so (load it through CUMF_ALS_LIB)")
+    _libmod.check(lib.cumf_set_debug_switches(int(switches)), "cumf_set_debug_switches")
+
+
+def last_kernel_name() -> str:
+    """Name of the Gram(+solve) kernel the last half-iteration dispatched, as rocprofv3 prints it."""
+    buf = C.create_string_buffer(256)
+    _libmod.check(_libmod.load().cumf_last_kernel_name(buf, 256), "cumf_last_kernel_name")
+    return buf.value.decode()
 
 
 def set_kernel_timing(enable: bool) -> None:

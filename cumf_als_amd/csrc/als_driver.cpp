@@ -164,6 +164,7 @@ extern "C" float cumf_doALS_ex(const int* csrRowIndexHostPtr, const int* csrColI
   };
 
   float final_rmse = 0;
+  bool range_error = false;
   if (!quiet) printf("*******start iterations...\n");
   for (int iter = 0; iter < ITERS; iter++) {
     half_iteration(sx, thetaT, XT);  // update X      (als.cu:727-855)
@@ -172,9 +173,13 @@ extern "C" float cumf_doALS_ex(const int* csrRowIndexHostPtr, const int* csrColI
       int flags = 0;
       DRV_CHECK(cumf_gram_fast_status(&flags));
       if (flags) {
+        // not a device failure: the opt-in arithmetic cannot represent this data.  Report and return NaN
+        // (cumf_last_error() == CUMF_ERR_FAST_RANGE); the factors are not copied back.
         fprintf(stderr, "doALS: gram mode \"fast\": %s beyond the f16 range (|value| >= 15.99) in iteration %d; "
                         "use CUMF_ALS_GRAM=split\n", (flags & 1) ? "a factor" : "a rating", iter);
-        exit(1);
+        cumf::set_last_error(CUMF_ERR_FAST_RANGE);
+        range_error = true;
+        break;
       }
     }
 
@@ -199,9 +204,11 @@ extern "C" float cumf_doALS_ex(const int* csrRowIndexHostPtr, const int* csrColI
     }
   }
   DRV_CHECK(hipDeviceSynchronize());
-  // copy feature vectors back to host (als.cu:1024-1025)
-  DRV_CHECK(hipMemcpy(thetaTHost, thetaT, (size_t)n * f * sizeof(float), hipMemcpyDeviceToHost));
-  DRV_CHECK(hipMemcpy(XTHost, XT, (size_t)m * f * sizeof(float), hipMemcpyDeviceToHost));
+  if (!range_error) {
+    // copy feature vectors back to host (als.cu:1024-1025)
+    DRV_CHECK(hipMemcpy(thetaTHost, thetaT, (size_t)n * f * sizeof(float), hipMemcpyDeviceToHost));
+    DRV_CHECK(hipMemcpy(XTHost, XT, (size_t)m * f * sizeof(float), hipMemcpyDeviceToHost));
+  }
 
   for (cumf_plan_t* p : sx.plans) cumf_plan_destroy(p);
   for (cumf_plan_t* p : st.plans) cumf_plan_destroy(p);
@@ -209,8 +216,9 @@ extern "C" float cumf_doALS_ex(const int* csrRowIndexHostPtr, const int* csrColI
                   cooVal_test, thetaT,  XT,      d_sse,  tt,          rhs};
   for (void* q : bufs)
     if (q) DRV_CHECK(hipFree(q));
+  DRV_CHECK(cumf_release_scratch());  // pooled tile buffers / pre-split tables of the plans above
   // the device is NOT reset here (als.cu:1031-1033: "WARN: do not call cudaDeviceReset inside ALS()")
-  return final_rmse;
+  return range_error ? nanf("") : final_rmse;
 }
 
 extern "C" float cumf_doALS(const int* csrRowIndexHostPtr, const int* csrColIndexHostPtr, const float* csrValHostPtr,

@@ -6,6 +6,13 @@
 
 #include <cstddef>
 
+// Profiling build (make ablate -> libALS_ablate.so): the kernels additionally honour KernelArgs::dbg, switches that
+// make the results WRONG on purpose (no solve, no Gram pass, ...) to time parts of a kernel.  The production
+// library compiles none of it and exports no way to set it.
+#ifndef CUMF_ABLATE
+#define CUMF_ABLATE 0
+#endif
+
 namespace cumf {
 
 constexpr int kThreads = 256;   // 4 waves of 64
@@ -67,6 +74,7 @@ struct KernelArgs {
   float* tt;       // f x f Gram per row; holds _Float16 when tt_half (CUMF_TT_FP16 of als.cu:335-441)
   float* rhs;
   int tt_half;
+  int tt_packed;   // tt receives the packed upper triangle, f (f + 1) / 2 floats per row (cumf_get_hermitian_packed)
   // dense_slots: item i (wave kernel) / row i (reduce kernel) of this launch uses slot i of `part` and
   // every item is dumped, none solved in place (batched "Gram -> tiles -> solver kernel" path)
   int dense_slots;
@@ -74,7 +82,7 @@ struct KernelArgs {
   int f;
   float lambda;
   int cg_iters;
-  int dbg;  // ablation switches for profiling (CUMF_ALS_DBG); 0 in production
+  int dbg;  // ablation switches; read only by the kernels of the profiling build (-DCUMF_ABLATE=1, libALS_ablate.so)
   // gram mode "fast": `gather` points at the pre-split (h, l) f16 words of the factor table
   // (presplit_f16x2_kernel) and range violations are OR-ed into *fast_flag (bit 0: table, bit 1: ratings)
   int fast_words;
@@ -116,7 +124,10 @@ bool wave_batched_path(int f, int mode);
 // `packed` receives the mirrored full matrices
 hipError_t launch_presplit(const float* src, unsigned* dst, size_t n, int* flag, hipStream_t stream);
 hipError_t launch_pack_upper(const float* full, float* packed, long batch, int f, int unpack, hipStream_t stream);
+void set_last_error(int code);  // read (and cleared) by cumf_last_error
 void set_kernel_timing(bool on);
+void note_item_kernel(const void* host_function);  // called by the launchers of the Gram(+solve) kernels
+const void* last_item_kernel();
 hipError_t last_kernel_ms(float* item_ms, float* reduce_ms);
 hipError_t launch_sse(const float* val, const int* row, const int* col, const float* thetaT, const float* XT,
                       long count, int f, int surpass_nan, double* out, hipStream_t stream);

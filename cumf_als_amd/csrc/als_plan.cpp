@@ -9,12 +9,18 @@
 // tile buffer that the reduce kernel sums in slot order (deterministic).
 #include <hip/hip_runtime.h>
 
+#include <cxxabi.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
 #include <numeric>
+#include <tuple>
 #include <vector>
 
 #include "als_internal.h"
@@ -45,12 +51,8 @@ struct cumf_plan {
   long long* d_c_begin = nullptr;
   int *d_w_row = nullptr, *d_w_len = nullptr, *d_w_rowlen = nullptr;
   long long* d_w_begin = nullptr;
-  float* d_part2 = nullptr;
-  long part2_rows = 0;
-  // gram mode "fast": rows of the gather table (cumf_plan_set_gather_rows) and its pre-split copy
+  // gram mode "fast": rows of the gather table (cumf_plan_set_gather_rows)
   long gather_rows = 0;
-  unsigned* d_words = nullptr;
-  size_t words_cap = 0;
 };
 
 namespace {
@@ -237,8 +239,7 @@ extern "C" int cumf_plan_destroy(cumf_plan_t* p) {
   void* ptrs[] = {p->d_item_row,  p->d_item_begin,  p->d_item_len,    p->d_item_slot,   p->d_item_rowlen,
                   p->d_mrow_row,  p->d_mrow_slot0,  p->d_mrow_nslots, p->d_mrow_rowlen, p->d_part,
                   p->d_c_row,     p->d_c_begin,     p->d_c_len,       p->d_c_slot,      p->d_c_rowlen,
-                  p->d_w_row,     p->d_w_begin,     p->d_w_len,       p->d_w_rowlen,    p->d_part2,
-                  p->d_words};
+                  p->d_w_row,     p->d_w_begin,     p->d_w_len,       p->d_w_rowlen};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   delete p;
@@ -262,31 +263,81 @@ extern "C" int cumf_plan_info(const cumf_plan_t* p, long info[4]) {
 
 namespace {
 
-// Dense-slot tile buffer of the batched path: at most 2 GiB (74 898 systems at f = 100), allocated on
-// first use and kept with the plan.  The CG path solves whole rows inside the Gram kernel and needs none.
-int plan_lists(const cumf_plan_t* cp, PlanLists* out, bool need_tiles = true) {
-  cumf_plan* p = const_cast<cumf_plan*>(cp);
-  const size_t tile_bytes = (size_t)p->nb * (p->nb + 1) / 2 * 256 * sizeof(float);
-  if (need_tiles && !p->d_part2 && p->n_witems > 0) {
-    long rows = (long)std::min<size_t>((size_t)p->n_witems, ((size_t)2 << 30) / tile_bytes);
-    if (rows < 1) rows = 1;
-    CUMF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p->d_part2), (size_t)rows * tile_bytes));
-    p->part2_rows = rows;
+// Scratch that outlives a call: the dense-slot tile buffer of the batched path (<= 2 GiB) and the pre-split
+// copy of the gather table (gram mode "fast").  Process-wide, grow-only, one buffer per (device, stream, kind):
+// calls on one stream are ordered, so the X_BATCH / THETA_BATCH plans of doALS and the pipeline pieces of
+// DistALS share ONE buffer instead of keeping 2 GiB each.  cumf_release_scratch frees them.
+enum { kScratchTiles = 0, kScratchWords = 1 };
+struct Scratch {
+  void* ptr = nullptr;
+  size_t cap = 0;
+};
+std::mutex g_scratch_mutex;
+std::map<std::tuple<int, hipStream_t, int>, Scratch> g_scratch;
+std::map<int, int*> g_fast_flag;  // per device (range report of gram mode "fast")
+
+int scratch_get(hipStream_t stream, int kind, size_t bytes, void** out) {
+  int dev = 0;
+  CUMF_HIP_CHECK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  Scratch& sc = g_scratch[std::make_tuple(dev, stream, kind)];
+  if (sc.cap < bytes) {
+    if (sc.ptr) {
+      CUMF_HIP_CHECK(hipStreamSynchronize(stream));  // kernels of earlier calls may still read it
+      CUMF_HIP_CHECK(hipFree(sc.ptr));
+      sc.ptr = nullptr;
+      sc.cap = 0;
+    }
+    CUMF_HIP_CHECK(hipMalloc(&sc.ptr, bytes));
+    sc.cap = bytes;
   }
-  *out = PlanLists{p->n_items,  p->n_mrows, p->n_citems, p->n_witems, p->d_c_row,    p->d_c_len,  p->d_c_slot,
-                   p->d_c_rowlen, p->d_c_begin, p->d_w_row,  p->d_w_len,  p->d_w_rowlen, p->d_w_begin, p->d_part2,
-                   p->part2_rows};
+  *out = sc.ptr;
   return 0;
 }
 
-// Ablation switches of the kernels (CUMF_ALS_DBG / cumf_set_debug_switches; 0 in production: any other
-// value makes the results wrong on purpose -- 1 = no solve, 2 = no Gram pass, 8 = every gather hits row 0,
-// 16 = no gather DMA).  bench.py uses 1 to time the Gram pass alone for the roofline of the Gram kernel.
+int fast_flag_get(int** out) {
+  int dev = 0;
+  CUMF_HIP_CHECK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  int*& flag = g_fast_flag[dev];
+  if (!flag) {
+    CUMF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&flag), sizeof(int)));
+    CUMF_HIP_CHECK(hipMemset(flag, 0, sizeof(int)));
+  }
+  *out = flag;
+  return 0;
+}
+
+// Work lists of the batched path; need_tiles: the dense-slot tile buffer (at most 2 GiB = 74 898 systems at
+// f = 100).  The CG path solves whole rows inside the Gram kernel and needs none.
+int plan_lists(const cumf_plan_t* p, PlanLists* out, hipStream_t stream, bool need_tiles = true) {
+  const size_t tile_bytes = (size_t)p->nb * (p->nb + 1) / 2 * 256 * sizeof(float);
+  float* part2 = nullptr;
+  long rows = 0;
+  if (need_tiles && p->n_witems > 0) {
+    rows = (long)std::min<size_t>((size_t)p->n_witems, ((size_t)2 << 30) / tile_bytes);
+    if (rows < 1) rows = 1;
+    void* q = nullptr;
+    const int rc = scratch_get(stream, kScratchTiles, (size_t)rows * tile_bytes, &q);
+    if (rc) return rc;
+    part2 = static_cast<float*>(q);
+  }
+  *out = PlanLists{p->n_items,  p->n_mrows, p->n_citems, p->n_witems, p->d_c_row,    p->d_c_len,  p->d_c_slot,
+                   p->d_c_rowlen, p->d_c_begin, p->d_w_row,  p->d_w_len,  p->d_w_rowlen, p->d_w_begin, part2,
+                   rows};
+  return 0;
+}
+
+#if CUMF_ABLATE
+// Ablation switches of the kernels, profiling build only (libALS_ablate.so; CUMF_ALS_DBG /
+// cumf_set_debug_switches): any value but 0 makes the results wrong on purpose -- 1 = no solve, 2 = no Gram
+// pass, 8 = every gather hits row 0, 16 = no gather DMA.
 int g_debug_switches = -1;
 int debug_switches() {
   if (g_debug_switches < 0) g_debug_switches = getenv("CUMF_ALS_DBG") ? atoi(getenv("CUMF_ALS_DBG")) : 0;
   return g_debug_switches;
 }
+#endif
 
 KernelArgs base_args(const cumf_plan_t* p, const int* colidx, const float* val, const float* gather, int f,
                      float lambda) {
@@ -307,37 +358,35 @@ KernelArgs base_args(const cumf_plan_t* p, const int* colidx, const float* val, 
   a.row_begin = p->row_begin;
   a.f = f;
   a.lambda = lambda;
+#if CUMF_ABLATE
   a.dbg = debug_switches();
+#endif
   return a;
 }
 
 // Gram mode "fast": the factor table as (h, l) f16 words, rebuilt per call (the factors change every
-// half-iteration: 2 x 192 MB of traffic for the Netflix X table, ~0.1 ms), kept with the plan.
-int* g_fast_flag = nullptr;
-int fast_words(cumf_plan_t* p, const float* gather, int f, hipStream_t stream, KernelArgs* a) {
+// half-iteration: 2 x 192 MB of traffic for the Netflix X table, ~0.1 ms).
+int fast_words(const cumf_plan_t* p, const float* gather, int f, hipStream_t stream, KernelArgs* a) {
   if (p->gather_rows <= 0) {
     fprintf(stderr, "cumf_als_update_fused: gram mode \"fast\" needs the row count of the gather table "
                     "(cumf_plan_set_gather_rows)\n");
     return (int)hipErrorInvalidValue;
   }
   const size_t n = (size_t)p->gather_rows * f;
-  if (p->words_cap < n) {
-    if (p->d_words) (void)hipFree(p->d_words);
-    p->d_words = nullptr;
-    p->words_cap = 0;
-    CUMF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p->d_words), n * sizeof(unsigned)));
-    p->words_cap = n;
-  }
-  if (!g_fast_flag) {
-    CUMF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g_fast_flag), sizeof(int)));
-    CUMF_HIP_CHECK(hipMemset(g_fast_flag, 0, sizeof(int)));
-  }
-  CUMF_HIP_CHECK(launch_presplit(gather, p->d_words, n, g_fast_flag, stream));
-  a->gather = reinterpret_cast<const float*>(p->d_words);
+  void* words = nullptr;
+  int rc = scratch_get(stream, kScratchWords, n * sizeof(unsigned), &words);
+  if (rc) return rc;
+  int* flag = nullptr;
+  rc = fast_flag_get(&flag);
+  if (rc) return rc;
+  CUMF_HIP_CHECK(launch_presplit(gather, static_cast<unsigned*>(words), n, flag, stream));
+  a->gather = reinterpret_cast<const float*>(words);
   a->fast_words = 1;
-  a->fast_flag = g_fast_flag;
+  a->fast_flag = flag;
   return 0;
 }
+
+int g_last_error = 0;
 
 }  // namespace
 
@@ -346,10 +395,66 @@ int fast_words(cumf_plan_t* p, const float* gather, int f, hipStream_t stream, K
 extern "C" int cumf_gram_fast_status(int* flags) {
   if (!flags) return (int)hipErrorInvalidValue;
   *flags = 0;
-  if (!g_fast_flag) return 0;
+  int dev = 0;
+  CUMF_HIP_CHECK(hipGetDevice(&dev));
+  int* flag = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    auto it = g_fast_flag.find(dev);
+    if (it != g_fast_flag.end()) flag = it->second;
+  }
+  if (!flag) return 0;
+  CUMF_HIP_CHECK(hipDeviceSynchronize());  // every stream: no kernel is OR-ing into the flag any more
+  CUMF_HIP_CHECK(hipMemcpy(flags, flag, sizeof(int), hipMemcpyDeviceToHost));
+  CUMF_HIP_CHECK(hipMemset(flag, 0, sizeof(int)));
+  return 0;
+}
+
+// Frees the pooled scratch of every device (tile buffers, pre-split tables, range flags); doALS calls it on exit.
+extern "C" int cumf_release_scratch(void) {
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
   CUMF_HIP_CHECK(hipDeviceSynchronize());
-  CUMF_HIP_CHECK(hipMemcpy(flags, g_fast_flag, sizeof(int), hipMemcpyDeviceToHost));
-  CUMF_HIP_CHECK(hipMemset(g_fast_flag, 0, sizeof(int)));
+  for (auto& kv : g_scratch)
+    if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+  g_scratch.clear();
+  for (auto& kv : g_fast_flag)
+    if (kv.second) (void)hipFree(kv.second);
+  g_fast_flag.clear();
+  return 0;
+}
+
+// Error state of the entry points that return a value instead of a code (cumf_doALS_ex returns NaN and sets
+// this): 0 = none, otherwise a HIP error code or one of CUMF_ERR_*.  Reading clears it.
+extern "C" int cumf_last_error(void) {
+  const int e = g_last_error;
+  g_last_error = 0;
+  return e;
+}
+void cumf::set_last_error(int code) { g_last_error = code; }
+
+// Demangled name of the Gram(+solve) kernel the last half-iteration of this process dispatched, as a profiler
+// prints it (e.g. "cumf::als_wave_kernel<7, 1, 100, 0>"); empty before the first launch.
+extern "C" int cumf_last_kernel_name(char* buf, int cap) {
+  if (!buf || cap <= 0) return (int)hipErrorInvalidValue;
+  buf[0] = 0;
+  const void* fn = last_item_kernel();
+  if (!fn) return 0;
+  const char* mangled = hipKernelNameRefByPtr(fn, nullptr);
+  if (!mangled) return 0;
+  int status = 0;
+  char* dem = abi::__cxa_demangle(mangled, nullptr, nullptr, &status);
+  const char* name = (status == 0 && dem) ? dem : mangled;
+  size_t len = strlen(name);
+  const char* paren = strchr(name, '(');  // drop the parameter list, and the "void " of a template instance
+  if (paren) len = (size_t)(paren - name);
+  if (strncmp(name, "void ", 5) == 0) {
+    name += 5;
+    len -= 5;
+  }
+  if (len >= (size_t)cap) len = (size_t)cap - 1;
+  memcpy(buf, name, len);
+  buf[len] = 0;
+  free(dem);
   return 0;
 }
 
@@ -378,19 +483,15 @@ extern "C" int cumf_als_update_fused(const cumf_plan_t* p, const int* colidx, co
   a.cg_iters = cg_iters;
   const int mode = (solver == CUMF_SOLVER_LU) ? kModeLU : kModeCG;
   PlanLists lists{};
-  // The tile round trip of the batched path is 2 x 28 KB per row at f = 100: worth it when the Gram of a
-  // row is long (Netflix: 206 .. 5 575 ratings per row: CG 29.4 -> 22.2 ms per iteration), not for
-  // hugewiki's 62-rating rows (measured 165 -> 186 ms), which stay on the fused workgroup kernel.
-  const long long plan_nnz_rows = p->row_end - p->row_begin;
-  const bool long_rows = plan_nnz_rows > 0 && p->plan_nnz / plan_nnz_rows >= 128;
-  (void)long_rows;
   const bool batched = wave_batched_path(f, mode);
   if (batched) {
-    const int rc = plan_lists(p, &lists, mode == kModeLU && p->nb > kMaxFusedLuWaveNB);  // else solved in the Gram kernel
+    // whole rows are solved inside the two-wave Gram kernel (CG always, LU up to NB = 9); only the larger LUs
+    // go through the dense-slot tile buffer
+    const int rc = plan_lists(p, &lists, static_cast<hipStream_t>(stream), mode == kModeLU && p->nb > kMaxFusedLuWaveNB);
     if (rc) return rc;
   }
   if (gram_mode() == kGramFast && (batched || wave_path_available(f, mode))) {
-    const int rc = fast_words(const_cast<cumf_plan_t*>(p), gather, f, static_cast<hipStream_t>(stream), &a);
+    const int rc = fast_words(p, gather, f, static_cast<hipStream_t>(stream), &a);
     if (rc) return rc;
   }
   CUMF_HIP_CHECK(launch_half_iteration(a, mode, p->n_items, p->n_mrows, static_cast<hipStream_t>(stream),
@@ -398,45 +499,48 @@ extern "C" int cumf_als_update_fused(const cumf_plan_t* p, const int* colidx, co
   return 0;
 }
 
-extern "C" int cumf_get_hermitian(const cumf_plan_t* p, const int* colidx, const float* val, const float* gather,
-                                  float* tt, float* rhs, int f, float lambda, void* stream) {
+namespace {
+// storage: 0 = fp32 f x f (both triangles), 1 = fp16 f x f, 2 = fp32 packed upper triangle
+int get_hermitian_any(const char* who, const cumf_plan_t* p, const int* colidx, const float* val, const float* gather,
+                      void* tt, float* rhs, int f, float lambda, void* stream, int storage) {
   if (!p || f != p->f) {
-    fprintf(stderr, "cumf_get_hermitian: plan/f mismatch\n");
+    fprintf(stderr, "%s: plan/f mismatch\n", who);
     return (int)hipErrorInvalidValue;
   }
   KernelArgs a = base_args(p, colidx, val, gather, f, lambda);
-  a.tt = tt;
+  a.tt = static_cast<float*>(tt);
+  a.tt_half = storage == 1;
+  a.tt_packed = storage == 2;
   a.rhs = rhs;
   PlanLists lists{};
   const bool batched = wave_batched_path(f, kModeMaterialize);
   if (batched) {
-    const int rc = plan_lists(p, &lists);
+    const int rc = plan_lists(p, &lists, static_cast<hipStream_t>(stream));
     if (rc) return rc;
   }
   CUMF_HIP_CHECK(launch_half_iteration(a, kModeMaterialize, p->n_items, p->n_mrows, static_cast<hipStream_t>(stream),
                                        batched ? &lists : nullptr));
   return 0;
 }
+}  // namespace
+
+extern "C" int cumf_get_hermitian(const cumf_plan_t* p, const int* colidx, const float* val, const float* gather,
+                                  float* tt, float* rhs, int f, float lambda, void* stream) {
+  return get_hermitian_any("cumf_get_hermitian", p, colidx, val, gather, tt, rhs, f, lambda, stream, 0);
+}
 
 extern "C" int cumf_get_hermitian_fp16(const cumf_plan_t* p, const int* colidx, const float* val, const float* gather,
                                        void* tt_half, float* rhs, int f, float lambda, void* stream) {
-  if (!p || f != p->f) {
-    fprintf(stderr, "cumf_get_hermitian_fp16: plan/f mismatch\n");
-    return (int)hipErrorInvalidValue;
-  }
-  KernelArgs a = base_args(p, colidx, val, gather, f, lambda);
-  a.tt = static_cast<float*>(tt_half);
-  a.tt_half = 1;
-  a.rhs = rhs;
-  PlanLists lists{};
-  const bool batched = wave_batched_path(f, kModeMaterialize);
-  if (batched) {
-    const int rc = plan_lists(p, &lists);
-    if (rc) return rc;
-  }
-  CUMF_HIP_CHECK(launch_half_iteration(a, kModeMaterialize, p->n_items, p->n_mrows, static_cast<hipStream_t>(stream),
-                                       batched ? &lists : nullptr));
-  return 0;
+  return get_hermitian_any("cumf_get_hermitian_fp16", p, colidx, val, gather, tt_half, rhs, f, lambda, stream, 1);
+}
+
+// The Gram batch as packed upper triangles, written straight from the accumulators: what the multi-GPU
+// Theta phase reduces across GPUs (hugewiki.cu:2703-2717 moves full f x f matrices) -- no f x f batch is
+// materialised and no pack pass runs.
+extern "C" int cumf_get_hermitian_packed(const cumf_plan_t* p, const int* colidx, const float* val,
+                                         const float* gather, float* packed, float* rhs, int f, float lambda,
+                                         void* stream) {
+  return get_hermitian_any("cumf_get_hermitian_packed", p, colidx, val, gather, packed, rhs, f, lambda, stream, 2);
 }
 
 extern "C" int cumf_cg_solve_batched_fp16(const void* A_half, float* x, const float* b, long batch, int f,
@@ -509,11 +613,14 @@ extern "C" int cumf_set_gram_mode(int mode) {
 }
 extern "C" int cumf_get_gram_mode(void) { return gram_mode(); }
 
+#if CUMF_ABLATE
+// profiling build only (not declared in include/): see debug_switches() above
 extern "C" int cumf_set_debug_switches(int switches) {
   if (switches < 0) return (int)hipErrorInvalidValue;
   g_debug_switches = switches;
   return 0;
 }
+#endif
 
 extern "C" int cumf_set_kernel_timing(int enable) {
   set_kernel_timing(enable != 0);

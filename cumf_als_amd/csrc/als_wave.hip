@@ -150,15 +150,21 @@ struct WaveGather {
   const int* idx_base;     // colidx + begin + 8 g
   long long last_off;      // last feature block: byte offset of this lane's load from the row pointer
   unsigned row_bytes;
-  int g, len, dbg;
+  int g, len;
+#if CUMF_ABLATE
+  int dbg;
+#endif
   bool is_feat, is_val;    // last feature block: this lane holds a feature / the rating slot
 
   __device__ __forceinline__ void init(const KernelArgs& a, int f, long long begin, int len_, int lane) {
     const int c = lane & 15;
     g = lane >> 4;
     len = len_;
-    row_bytes = (a.dbg & 8) ? 0u : (unsigned)f * 4u;  // ablation: every gather hits row 0
+    row_bytes = (unsigned)f * 4u;
+#if CUMF_ABLATE
+    if (a.dbg & 8) row_bytes = 0u;  // ablation: every gather hits row 0
     dbg = a.dbg;
+#endif
     lane_base = reinterpret_cast<const char*>(a.gather) + 4 * c;
     zero_base = reinterpret_cast<const char*>(g_wave_zeros) + 4 * c;
     const int fi = 16 * (NB - 1) + c;
@@ -379,7 +385,10 @@ __device__ __forceinline__ void stage_step(const WaveGather<NB>& wg, Planes<NB, 
   static_for<8>([&](auto ec) { wg.template finish_one<decltype(ec)::value, ARITH>(R); });  // consumes R.rv
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the chunks are in registers, the buffer is free
   if constexpr (KIND == kStepFull) {
-    if (!(wg.dbg & 16)) wg.template dma_issue<true>(R, lds, s_next);  // consumes R.idx
+#if CUMF_ABLATE
+    if (!(wg.dbg & 16))  // ablation: no gather DMA
+#endif
+      wg.template dma_issue<true>(R, lds, s_next);  // consumes R.idx
     wg.template load_val<true>(R, s_next);
     wg.template load_idx<true>(R, s_idx);
   } else if constexpr (KIND == kStepPartial) {
@@ -418,7 +427,8 @@ __device__ __forceinline__ void wave_tiles_to_partial(const f32x4 (&acc)[NB * (N
 // row-major f x f Gram, both triangles, lambda * n on the diagonal (als.cu:545-566) + RHS
 template <int NB, typename T>
 __device__ __forceinline__ void wave_tiles_to_global(const f32x4 (&acc)[NB * (NB + 1) / 2], T* __restrict__ tt,
-                                                     float* __restrict__ rhs, int f, float reg, int lane) {
+                                                     float* __restrict__ rhs, int f, float reg, int lane,
+                                                     bool packed = false) {
   const int c = lane & 15, kk = lane >> 4;
   static_for<NB*(NB + 1) / 2>([&](auto tc) {
     constexpr int t = decltype(tc)::value;
@@ -433,8 +443,12 @@ __device__ __forceinline__ void wave_tiles_to_global(const f32x4 (&acc)[NB * (NB
         // temp): inside a diagonal tile the split products reach (i, j) and (j, i) in different orders, so
         // only the upper entry is used there
         if (I != J || i <= j) {
-          tt[(size_t)i * f + j] = (T)v;  // T = _Float16: fp16 Gram storage (als.cu:335-441), round to nearest even
-          if (i != j) tt[(size_t)j * f + i] = (T)v;
+          if (packed) {  // row i keeps columns i .. f - 1 (cumf_get_hermitian_packed)
+            tt[(size_t)i * f - (size_t)(i * (i - 1) / 2) + (j - i)] = (T)v;
+          } else {
+            tt[(size_t)i * f + j] = (T)v;  // T = _Float16: fp16 Gram storage (als.cu:335-441), round to nearest even
+            if (i != j) tt[(size_t)j * f + i] = (T)v;
+          }
         }
       } else if (i < f && j == f && rhs != nullptr) {
         rhs[i] = v;
@@ -973,8 +987,12 @@ __global__ __launch_bounds__(64, CUMF_WAVE_MIN_WAVES) void als_wave_kernel(const
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // a.dbg: ablation switches for profiling (CUMF_ALS_DBG; results are wrong): 2 = no Gram pass
+#if CUMF_ABLATE
+  // the profiling build only (libALS_ablate.so, -DCUMF_ABLATE=1; results are wrong on purpose): 2 = no Gram pass
   const int nst = (a.dbg & 2) ? 0 : (len + kWaveStage - 1) / kWaveStage;
+#else
+  const int nst = (len + kWaveStage - 1) / kWaveStage;
+#endif
   const int nfull = len / kWaveStage;
   if (nst > 0) {
     WaveGather<NB> wg;
@@ -1003,6 +1021,7 @@ __global__ __launch_bounds__(64, CUMF_WAVE_MIN_WAVES) void als_wave_kernel(const
     return;
   }
   const float reg = (float)rowlen * a.lambda;  // als.cu:547: (end - start) * lambda
+#if CUMF_ABLATE
   if (a.dbg & 1) {  // ablation: no solve (keep the accumulators alive)
     float sum = 0.f;
 #pragma unroll
@@ -1010,13 +1029,14 @@ __global__ __launch_bounds__(64, CUMF_WAVE_MIN_WAVES) void als_wave_kernel(const
     if (lane < f) a.update[(size_t)row * f + lane] = sum;
     return;
   }
+#endif
   if constexpr (MODE == kModeMaterialize) {
-    const size_t off = (size_t)(row - a.row_begin) * f * f;
+    const size_t off = (size_t)(row - a.row_begin) * (a.tt_packed ? (size_t)f * (f + 1) / 2 : (size_t)f * f);
     float* rhs = a.rhs ? a.rhs + (size_t)(row - a.row_begin) * f : nullptr;
     if (a.tt_half)
       wave_tiles_to_global<NB>(acc, reinterpret_cast<_Float16*>(a.tt) + off, rhs, f, reg, lane);
     else
-      wave_tiles_to_global<NB>(acc, a.tt + off, rhs, f, reg, lane);
+      wave_tiles_to_global<NB>(acc, a.tt + off, rhs, f, reg, lane, a.tt_packed != 0);
   } else if constexpr (MODE == kModeCG) {
     cg_wave_core<NB, 1, 0>(acc, smem, a, f, row, rowlen, lane);  // the reference's default solver (als.cu:28)
   } else {
@@ -1124,6 +1144,15 @@ __device__ __forceinline__ void multi_body(float* smem, const KernelArgs& a, lon
   // a whole row (no slot): the two waves solve it where the tiles are -- 93 KB per row at f = 200 that
   // neither go out to HBM nor come back (measured: 45 GB each way per Netflix X half-iteration)
   if (slot < 0) {
+#if CUMF_ABLATE
+    if (a.dbg & 1) {  // ablation: no solve (keep the accumulators alive)
+      float sum = 0.f;
+#pragma unroll
+      for (int s = 0; s < TPW; ++s) sum += (acc[s][0] + acc[s][1]) + (acc[s][2] + acc[s][3]);
+      if (64 * W + lane < f) a.update[(size_t)row * f + 64 * W + lane] = sum;
+      return;
+    }
+#endif
     if constexpr (MODE == kModeCG) {
       cg_wave_core<NB, NW, W>(acc, smem, a, f, row, rowlen, lane);
     } else {
@@ -1159,47 +1188,6 @@ __global__ __launch_bounds__(64 * NW, NB >= 10 ? 1 : 2) void als_wave_multi_kern
     multi_body<NB, NW, 1, MODE, ARITH>(smem, a, begin, len, slot, row, rowlen, lane);
 }
 
-// ----------------------------------------------------------------------------------
-// Solver kernel on dumped tiles: one wave per row sums the row's slots (a fixed, deterministic order)
-// into a full tile set and runs the single-wave LU above.  At f = 200 that is 91 tiles = 364
-// accumulator registers of a 512-register wave -- against the 4-wave lu_solve_mfma whose 95 KB row
-// store leaves ONE workgroup per CU (measured: 121 ms per Netflix iteration at f = 200).
-// ----------------------------------------------------------------------------------
-template <int NB, int MODE>
-__global__ __launch_bounds__(64, NB >= 10 ? 1 : 2) void als_wave_solve_kernel(const KernelArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int NT = NB * (NB + 1) / 2;
-  const int lane = threadIdx.x;
-  const int mr = blockIdx.x;
-  const int row = a.mrow_row[mr];
-  const int slot0 = a.dense_slots ? mr : a.mrow_slot0[mr];
-  const int nslots = a.dense_slots ? 1 : a.mrow_nslots[mr];
-  const int rowlen = a.mrow_rowlen[mr];
-  const int f = a.f;
-  f32x4 acc[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int sl = 0; sl < nslots; ++sl) {
-    const float* part = a.part + (size_t)(slot0 + sl) * NT * 256;
-    static_for<NT>([&](auto tc) {
-      constexpr int t = decltype(tc)::value;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[t][r] += part[((size_t)t * 4 + r) * 64 + lane];
-    });
-  }
-  const float reg = (float)rowlen * a.lambda;  // als.cu:547
-  if constexpr (MODE == kModeMaterialize) {
-    const size_t off = (size_t)(row - a.row_begin) * f * f;
-    float* rhs = a.rhs ? a.rhs + (size_t)(row - a.row_begin) * f : nullptr;
-    if (a.tt_half)
-      wave_tiles_to_global<NB>(acc, reinterpret_cast<_Float16*>(a.tt) + off, rhs, f, reg, lane);
-    else
-      wave_tiles_to_global<NB>(acc, a.tt + off, rhs, f, reg, lane);
-  } else {
-    lu_wave<NB, 0>(acc, smem, f, reg, a.update + (size_t)row * f, lane);
-  }
-}
-
 // This file is compiled twice per NB <= 7 (Makefile): part 0 holds everything but the LU form of
 // als_wave_kernel, part 1 only that (wave_lu_launch), built with -mllvm -enable-misched=false: the pre-RA
 // machine scheduler triples the accumulator spills at the Gram -> LU hand-over of that kernel (125 vs 38
@@ -1217,20 +1205,14 @@ hipError_t wave_solve_launch(const KernelArgs& a, int mode, long n_rows, hipStre
 template <>
 hipError_t wave_solve_launch<CUMF_WAVE_NB>(const KernelArgs& a, int mode, long n_rows, hipStream_t stream) {
   if (n_rows <= 0) return hipSuccess;
-  if (mode == kModeMaterialize) {
-    hipLaunchKernelGGL((als_wave_solve_kernel<CUMF_WAVE_NB, kModeMaterialize>), dim3((unsigned)n_rows), dim3(64), 0,
-                       stream, a);
-  } else if (mode == kModeLU) {
-    const size_t lds = wave_lu_lds_floats<CUMF_WAVE_NB>(a.f) * sizeof(float);
-    hipLaunchKernelGGL((als_wave_solve_kernel<CUMF_WAVE_NB, kModeLU>), dim3((unsigned)n_rows), dim3(64), lds, stream, a);
+  if (mode != kModeCG) {
+    return hipErrorInvalidValue;  // LU / materialise of dumped tiles: als_reduce_kernel (als_kernels.hip)
   } else if (mode == kModeCG) {
     // the tiles are VALU operands (VGPRs only): 91 tiles at NB = 13 = four waves x 23 tiles next to the five
     // vectors, at two waves per SIMD
     constexpr int NW = CUMF_WAVE_NB >= 10 ? 4 : 1;
     const size_t lds = NW > 1 ? (size_t)NW * CUMF_WAVE_NB * 16 * sizeof(float) : 0;
     hipLaunchKernelGGL((als_wave_cg_kernel<CUMF_WAVE_NB, NW>), dim3((unsigned)n_rows), dim3(64 * NW), lds, stream, a);
-  } else {
-    return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
@@ -1253,6 +1235,7 @@ static hipError_t launch_wave_lu(const KernelArgs& a, long n_items, hipStream_t 
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
+  note_item_kernel(reinterpret_cast<const void*>(als_wave_kernel<NB, kModeLU, FC, ARITH>));
   hipLaunchKernelGGL((als_wave_kernel<NB, kModeLU, FC, ARITH>), dim3((unsigned)n_items), dim3(64), lds, stream, a);
   return hipGetLastError();
 }
@@ -1278,9 +1261,11 @@ static hipError_t launch_wave_fc(const KernelArgs& a, int mode, long n_items, hi
   const size_t stage_lds = wave_stage_lds_floats<NB>() * sizeof(float);
   if (mode == kModeMaterialize) {
     if constexpr (ARITH != kArithSplit3) return hipErrorInvalidValue;  // materialise: the 24-bit arithmetic only
+    note_item_kernel(reinterpret_cast<const void*>(als_wave_kernel<NB, kModeMaterialize, FC, kArithSplit3>));
     hipLaunchKernelGGL((als_wave_kernel<NB, kModeMaterialize, FC, kArithSplit3>), dim3((unsigned)n_items), dim3(64),
                        stage_lds, stream, a);
   } else if (mode == kModeCG) {
+    note_item_kernel(reinterpret_cast<const void*>(als_wave_kernel<NB, kModeCG, FC, ARITH>));
     hipLaunchKernelGGL((als_wave_kernel<NB, kModeCG, FC, ARITH>), dim3((unsigned)n_items), dim3(64), stage_lds, stream, a);
   } else {
     return wave_lu_launch<NB>(a, n_items, stream);  // part 1 of this file (picks FC and the arithmetic itself)
@@ -1298,20 +1283,20 @@ hipError_t wave_item_launch<CUMF_WAVE_NB>(const KernelArgs& a, int mode, long n_
   // als_lu_wg.h with two wave roles), items with one dump their tiles
   size_t lds = 2 * wave_stage_lds_floats<CUMF_WAVE_NB>() * sizeof(float);  // double-buffered stages
   if (lu_wg_lds_floats<CUMF_WAVE_NB>(a.f) * sizeof(float) > lds) lds = lu_wg_lds_floats<CUMF_WAVE_NB>(a.f) * sizeof(float);
+  auto go = [&](auto kernel) {
+    note_item_kernel(reinterpret_cast<const void*>(kernel));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)n_items), dim3(128), lds, stream, a);
+  };
   if (a.fast_words) {
     if (mode == kModeMaterialize) return hipErrorInvalidValue;
     if (mode == kModeCG)
-      hipLaunchKernelGGL((als_wave_multi_kernel<CUMF_WAVE_NB, 2, kModeCG, kArithFast>), dim3((unsigned)n_items),
-                         dim3(128), lds, stream, a);
+      go(als_wave_multi_kernel<CUMF_WAVE_NB, 2, kModeCG, kArithFast>);
     else
-      hipLaunchKernelGGL((als_wave_multi_kernel<CUMF_WAVE_NB, 2, kModeLU, kArithFast>), dim3((unsigned)n_items),
-                         dim3(128), lds, stream, a);
+      go(als_wave_multi_kernel<CUMF_WAVE_NB, 2, kModeLU, kArithFast>);
   } else if (mode == kModeCG) {
-    hipLaunchKernelGGL((als_wave_multi_kernel<CUMF_WAVE_NB, 2, kModeCG>), dim3((unsigned)n_items), dim3(128), lds,
-                       stream, a);
+    go(als_wave_multi_kernel<CUMF_WAVE_NB, 2, kModeCG, kArithSplit3>);
   } else {
-    hipLaunchKernelGGL((als_wave_multi_kernel<CUMF_WAVE_NB, 2, kModeLU>), dim3((unsigned)n_items), dim3(128), lds,
-                       stream, a);
+    go(als_wave_multi_kernel<CUMF_WAVE_NB, 2, kModeLU, kArithSplit3>);
   }
   return hipGetLastError();
 #else

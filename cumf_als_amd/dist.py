@@ -112,6 +112,10 @@ class HipOps:
     def get_hermitian(self, plan, colidx, val, gather, lam, tt, rhs):
         self.als.get_hermitian(plan, colidx, val, gather, lam, tt, rhs)
 
+    def get_hermitian_packed(self, plan, colidx, val, gather, lam, packed, rhs):
+        """Partial Gram batch as packed upper triangles, straight from the accumulators (no f x f batch)."""
+        self.als.get_hermitian_packed(plan, colidx, val, gather, lam, packed, rhs)
+
     def solve(self, tt, rhs, x, solver, cg_iters):
         if solver in ("cg", 0):
             self.als.cg_solve(tt, x, rhs, cg_iters)
@@ -216,6 +220,8 @@ class PipelinedGather:
 
     def issue(self, c: int, piece: torch.Tensor) -> None:
         """Piece c of this rank's slab is final: start its all-gather."""
+        if self.mx[c] == 0:   # empty on every rank (identical decision everywhere: mx comes from the global row pointer)
+            return
         self.send[c][: piece.shape[0]].copy_(piece)
         recv = self.recv[int(self.off[c]): int(self.off[c + 1])]
         self.works.append(dist.all_gather_into_tensor(recv, self.send[c], group=self.group, async_op=True))
@@ -292,9 +298,11 @@ class DistALS:
     `scheme="reduce"`, at least its own row slab -- see `from_local_slab`)."""
 
     def __init__(self, mat: HostMatrix, f: int, lam: float, ops, solver="cg", cg_iters: int = 6,
-                 scheme: str = "gather", theta_batch: int = 1, group=None, chunk: int = 0):
+                 scheme: str = "gather", theta_batch: int = 1, group=None, chunk: int = 0, solver_x=None,
+                 solver_theta=None, cg_iters_x=None, cg_iters_theta=None):
         self.f, self.lam, self.ops = f, float(lam), ops
         self.solver, self.cg_iters, self.scheme = solver, cg_iters, scheme
+        self._set_side_solvers(solver_x, solver_theta, cg_iters_x, cg_iters_theta)
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
@@ -322,6 +330,8 @@ class DistALS:
             self.t_rows = t1 - t0
             self.t_plan = ops.plan(rp, f, chunk)
             self.t_colidx, self.t_val = ops.to_device(ci), ops.to_device(va)
+            # the Theta all-gather is the big one (n x f: 192 MB at the Netflix shape): pipelined like X
+            self._t_pipe = self._make_pipeline(mat.csc_indptr, np.asarray(rp), self.tb, chunk)
         elif scheme == "reduce":
             # X slab only (device-resident for the whole run); slab-local CSC for the partial Grams
             self.XT = torch.zeros((self.x_rows, f), dtype=torch.float32, device=dev)
@@ -337,23 +347,35 @@ class DistALS:
             raise ValueError(scheme)
         self._setup_comm()
 
-    def _make_x_pipeline(self, rowptr_global, rowptr_local, chunk: int) -> None:
-        """X update in pieces with the all-gather of each piece under the next one (`PipelinedGather`);
-        CUMF_ALS_PIPE_CHUNKS pieces (default 4; 1 = one kernel + one blocking all-gather)."""
+    def _set_side_solvers(self, solver_x, solver_theta, cg_iters_x, cg_iters_theta) -> None:
+        """Per-side solver: the reference's hugewiki run solves X with CG, 100 iterations (hugewiki.cu:2569), and
+        Theta with the batched LU on the reduced Gram (hugewiki.cu:2732); `solver` / `cg_iters` are the defaults
+        of both sides."""
+        self.solver_x = self.solver if solver_x is None else solver_x
+        self.solver_theta = self.solver if solver_theta is None else solver_theta
+        self.cg_iters_x = self.cg_iters if cg_iters_x is None else cg_iters_x
+        self.cg_iters_theta = self.cg_iters if cg_iters_theta is None else cg_iters_theta
+
+    def _make_pipeline(self, rowptr_global, rowptr_local, bounds, chunk: int):
+        """One side's update in pieces with the all-gather of each piece under the next one (`PipelinedGather`);
+        CUMF_ALS_PIPE_CHUNKS pieces (default 4; 1 = one kernel + one blocking all-gather).  Returns
+        (piece bounds [world, chunks + 1], [(lo, hi, plan)] of this rank) or None."""
         import os
 
         chunks = int(os.environ.get("CUMF_ALS_PIPE_CHUNKS", "4"))
-        self._x_pipe = None
         force = os.environ.get("CUMF_ALS_PIPE_FORCE") == "1"  # tests: the RCCL path with world_size 1
         if chunks <= 1 or not dist.is_initialized() or (self.world <= 1 and not force):
-            return
-        pb = pipeline_bounds(rowptr_global, self.xb, chunks)
-        x0 = int(self.xb[self.rank])
+            return None
+        pb = pipeline_bounds(rowptr_global, bounds, chunks)
+        r0 = int(bounds[self.rank])
         plans = []
         for c in range(chunks):
-            lo, hi = int(pb[self.rank, c]) - x0, int(pb[self.rank, c + 1]) - x0
+            lo, hi = int(pb[self.rank, c]) - r0, int(pb[self.rank, c + 1]) - r0
             plans.append((lo, hi, self.ops.plan(rowptr_local, self.f, chunk, lo, hi) if hi > lo else None))
-        self._x_pipe = (pb, plans)
+        return (pb, plans)
+
+    def _make_x_pipeline(self, rowptr_global, rowptr_local, chunk: int) -> None:
+        self._x_pipe = self._make_pipeline(rowptr_global, rowptr_local, self.xb, chunk)
 
     def _setup_comm(self) -> None:
         """Persistent communication buffers (nothing is allocated or zero-filled
@@ -365,16 +387,19 @@ class DistALS:
             self._gt = SlabGather(self.tb, f, torch.float32, dev, self.group)
             self._px = PipelinedGather(self._x_pipe[0], self.m, f, torch.float32, dev, self.group) \
                 if getattr(self, "_x_pipe", None) is not None else None
+            self._pt = PipelinedGather(self._t_pipe[0], self.n, f, torch.float32, dev, self.group) \
+                if getattr(self, "_t_pipe", None) is not None else None
             return
         # reduce scheme.  Per Theta batch: k = ceil(size / world) systems per rank.  Two sets of
         # buffers so that the reduce-scatter of batch b runs (RCCL stream) under the Gram pass of
         # batch b + 1 (compute stream).  Payload = packed upper triangles (f (f + 1) / 2 floats per
-        # system instead of f * f: 0.80 GB instead of 1.59 GB per hugewiki Theta batch at f = 100)
-        # + the RHS (f floats per system) as a second, small collective.
+        # system instead of f * f: 0.80 GB instead of 1.59 GB per hugewiki Theta batch at f = 100),
+        # written by the Gram kernels straight from their accumulators (cumf_get_hermitian_packed: no
+        # f x f partial batch, no pack pass), + the RHS (f floats per system) as a second, small collective.
         self._kmax = max((size + w - 1) // w for (_, size, _) in self.t_batches)
         self._pk = f * (f + 1) // 2
         nb = 2 if len(self.t_batches) > 1 else 1
-        self._tt = [torch.empty((w * self._kmax, f, f), dtype=torch.float32, device=dev) for _ in range(nb)]
+        self._nbuf = nb
         self._rhs = [torch.empty((w * self._kmax, f), dtype=torch.float32, device=dev) for _ in range(nb)]
         self._tri = [torch.zeros((w * self._kmax, self._pk), dtype=torch.float32, device=dev) for _ in range(nb)]
         self._mine = [torch.empty((self._kmax, self._pk), dtype=torch.float32, device=dev) for _ in range(nb)]
@@ -386,13 +411,15 @@ class DistALS:
 
     @classmethod
     def from_device_ratings(cls, r, f: int, lam: float, ops, solver="cg", cg_iters: int = 6, group=None,
-                            chunk: int = 0) -> "DistALS":
+                            chunk: int = 0, solver_x=None, solver_theta=None, cg_iters_x=None,
+                            cg_iters_theta=None) -> "DistALS":
         """`gather` scheme from a `datagen.Ratings` that is already on this rank's device: the slabs are
         zero-copy views of its CSR / CSC arrays (no host round trip of the 1.6 GB matrix; only the two
         row-pointer arrays, a few MB, go to the host for the plans)."""
         self = cls.__new__(cls)
         self.f, self.lam, self.ops = f, float(lam), ops
         self.solver, self.cg_iters, self.scheme = solver, cg_iters, "gather"
+        self._set_side_solvers(solver_x, solver_theta, cg_iters_x, cg_iters_theta)
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -410,6 +437,7 @@ class DistALS:
         self.x_plan = ops.plan(rp[x0:x1 + 1] - rp[x0], f, chunk)
         self.t_plan = ops.plan(cp[t0:t1 + 1] - cp[t0], f, chunk)
         self._make_x_pipeline(rp, rp[x0:x1 + 1] - rp[x0], chunk)
+        self._t_pipe = self._make_pipeline(cp, cp[t0:t1 + 1] - cp[t0], self.tb, chunk)
         self.x_colidx, self.x_val = r.csr_indices[rp[x0]:rp[x1]], r.csr_data[rp[x0]:rp[x1]]
         self.t_colidx, self.t_val = r.csc_indices[cp[t0]:cp[t1]], r.csc_data[cp[t0]:cp[t1]]
         self._setup_comm()
@@ -418,7 +446,8 @@ class DistALS:
     @classmethod
     def from_local_slab(cls, m_total: int, n: int, xb, rowptr_l: torch.Tensor, colidx_l: torch.Tensor,
                         val_l: torch.Tensor, f: int, lam: float, ops, solver="cg", cg_iters: int = 6,
-                        theta_batch: int = 1, group=None, chunk: int = 0) -> "DistALS":
+                        theta_batch: int = 1, group=None, chunk: int = 0, solver_x=None, solver_theta=None,
+                        cg_iters_x=None, cg_iters_theta=None) -> "DistALS":
         """`reduce` scheme from this rank's row slab only (hugewiki scale: no rank ever holds the
         whole matrix -- the reference pre-splits it into per-GPU files, hugewiki.cu:2332-2340).
         `xb`: the world+1 global slab boundaries; the three tensors are the slab's CSR with the
@@ -426,6 +455,7 @@ class DistALS:
         self = cls.__new__(cls)
         self.f, self.lam, self.ops = f, float(lam), ops
         self.solver, self.cg_iters, self.scheme = solver, cg_iters, "reduce"
+        self._set_side_solvers(solver_x, solver_theta, cg_iters_x, cg_iters_theta)
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -470,37 +500,38 @@ class DistALS:
         return out
 
     # -- half-iterations -------------------------------------------------------------------
+    def _update_gathered(self, pipe, pg, gather_all, plan, colidx, val, table, out, bounds, solver, cg_iters) -> None:
+        """`gather` scheme, one side: this rank's slab of `out` from the replicated `table`, then the slabs of
+        all ranks exchanged -- piece by piece under the next piece's kernel when a pipeline exists."""
+        r0, r1 = int(bounds[self.rank]), int(bounds[self.rank + 1])
+        mine = out[r0:r1]
+        if pg is not None:
+            for c, (lo, hi, piece_plan) in enumerate(pipe[1]):
+                if piece_plan is not None:
+                    self.ops.update_fused(piece_plan, colidx, val, table, mine, self.lam, solver, cg_iters)
+                pg.issue(c, mine[lo:hi])
+            pg.finish(out)
+            return
+        self.ops.update_fused(plan, colidx, val, table, mine, self.lam, solver, cg_iters)
+        gather_all(out, mine)
+
     def update_x(self) -> None:
         if self.scheme == "gather":
-            x0, x1 = int(self.xb[self.rank]), int(self.xb[self.rank + 1])
-            mine = self.XT[x0:x1]
-            if self._px is not None:
-                for c, (lo, hi, plan) in enumerate(self._x_pipe[1]):
-                    if plan is not None:
-                        self.ops.update_fused(plan, self.x_colidx, self.x_val, self.thetaT, mine, self.lam,
-                                              self.solver, self.cg_iters)
-                    self._px.issue(c, mine[lo:hi])
-                self._px.finish(self.XT)
-                return
-            self.ops.update_fused(self.x_plan, self.x_colidx, self.x_val, self.thetaT, mine, self.lam,
-                                  self.solver, self.cg_iters)
-            self._gx(self.XT, mine)
+            self._update_gathered(self._x_pipe, self._px, self._gx, self.x_plan, self.x_colidx, self.x_val,
+                                  self.thetaT, self.XT, self.xb, self.solver_x, self.cg_iters_x)
         else:
             self.ops.update_fused(self.x_plan, self.x_colidx, self.x_val, self.thetaT, self.XT, self.lam,
-                                  self.solver, self.cg_iters)
+                                  self.solver_x, self.cg_iters_x)
 
     def update_theta(self) -> None:
         if self.scheme == "gather":
-            t0, t1 = int(self.tb[self.rank]), int(self.tb[self.rank + 1])
-            mine = self.thetaT[t0:t1]
-            self.ops.update_fused(self.t_plan, self.t_colidx, self.t_val, self.XT, mine, self.lam,
-                                  self.solver, self.cg_iters)
-            self._gt(self.thetaT, mine)
+            self._update_gathered(self._t_pipe, self._pt, self._gt, self.t_plan, self.t_colidx, self.t_val,
+                                  self.XT, self.thetaT, self.tb, self.solver_theta, self.cg_iters_theta)
             return
         # reduce scheme (replaces hugewiki.cu:2611-2745).  Pipeline over the Theta batches:
-        #   Gram(b) -> pack -> reduce-scatter(b) [async, RCCL stream]   ||   Gram(b + 1) ...
+        #   packed Gram(b) -> reduce-scatter(b) [async, RCCL stream]   ||   packed Gram(b + 1) ...
         #   wait(b) -> unpack -> solve(b) -> all-gather(b)
-        f, w, pk = self.f, self.world, self._pk
+        f, w = self.f, self.world
         pending = None  # (batch index, buffer set, work handle)
 
         def finish(bi, slot, works):
@@ -514,20 +545,19 @@ class DistALS:
             if hi > lo:
                 self.ops.unpack_upper(self._mine[slot][: hi - lo], self._my_tt[: hi - lo])
                 x[: hi - lo].copy_(self.thetaT[off + lo: off + hi])          # CG warm start
-                self.ops.solve(self._my_tt[: hi - lo], self._mine_rhs[slot][: hi - lo], x[: hi - lo], self.solver,
-                               self.cg_iters)
+                self.ops.solve(self._my_tt[: hi - lo], self._mine_rhs[slot][: hi - lo], x[: hi - lo],
+                               self.solver_theta, self.cg_iters_theta)
             gathered = self._gathered[: w * k]
             all_gather_equal(gathered, x, self.group)        # replaces hugewiki.cu:2744-2745
             self.thetaT[off: off + size].copy_(gathered[:size])
 
         overlap = len(self.t_batches) > 1
         for bi, (off, size, plan) in enumerate(self.t_batches):
-            slot = bi % len(self._tt)
+            slot = bi % self._nbuf
             k = (size + w - 1) // w
-            tt, rhs, tri = self._tt[slot][: w * k], self._rhs[slot][: w * k], self._tri[slot][: w * k]
-            # partial Gram / RHS over this rank's X slab (hugewiki.cu:2668-2679)
-            self.ops.get_hermitian(plan, self.lc_rowidx, self.lc_val, self.XT, self.lam, tt[:size], rhs[:size])
-            self.ops.pack_upper(tt[:size], tri[:size])
+            rhs, tri = self._rhs[slot][: w * k], self._tri[slot][: w * k]
+            # partial Gram / RHS over this rank's X slab (hugewiki.cu:2668-2679), as packed upper triangles
+            self.ops.get_hermitian_packed(plan, self.lc_rowidx, self.lc_val, self.XT, self.lam, tri[:size], rhs[:size])
             if size < w * k:  # the padding systems behind the last rank's share (a few rows, not the buffer)
                 tri[size:].zero_()
                 rhs[size:].zero_()

@@ -30,8 +30,11 @@ from .dist import DistALS, HipOps
 
 
 def run(split_dir: str, n: int, f: int, lam: float, iters: int, solver: str = "cg", cg_iters: int = 6,
-        theta_batch: int = 1, ops=None, quiet: bool = False):
-    """Body of one rank.  `ops` defaults to the HIP kernels on this rank's GPU."""
+        theta_batch: int = 1, ops=None, quiet: bool = False, solver_x=None, solver_theta=None, cg_iters_x=None,
+        cg_iters_theta=None):
+    """Body of one rank.  `ops` defaults to the HIP kernels on this rank's GPU.  solver_x / solver_theta /
+    cg_iters_x / cg_iters_theta override `solver` / `cg_iters` per side: the reference's own hugewiki run is
+    solver_x="cg", cg_iters_x=100 (hugewiki.cu:2569), solver_theta="lu" (hugewiki.cu:2732) = `--reference-solvers`."""
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     bounds = np.array(open(os.path.join(split_dir, "slabs.txt")).read().split(), dtype=np.int64)
@@ -45,7 +48,8 @@ def run(split_dir: str, n: int, f: int, lam: float, iters: int, solver: str = "c
     rowptr = torch.from_numpy(slab["csr_indptr"].astype(np.int64))
     colidx, val = to_dev(slab["csr_indices"]), to_dev(slab["csr_data"])
     eng = DistALS.from_local_slab(int(bounds[-1]), n, bounds, rowptr.to(colidx.device), colidx, val, f, lam, ops,
-                                  solver=solver, cg_iters=cg_iters, theta_batch=theta_batch)
+                                  solver=solver, cg_iters=cg_iters, theta_batch=theta_batch, solver_x=solver_x,
+                                  solver_theta=solver_theta, cg_iters_x=cg_iters_x, cg_iters_theta=cg_iters_theta)
     thetaT = np.empty((n, f), np.float32)
     _libmod.load().cumf_rand_init(thetaT.ctypes.data_as(C.c_void_p), n * f, 0.2, 0)
     eng.thetaT.copy_(torch.from_numpy(thetaT))
@@ -85,7 +89,17 @@ def main(argv=None) -> int:
     ap.add_argument("--solver", choices=["cg", "lu"], default="cg")
     ap.add_argument("--cg-iters", type=int, default=6)
     ap.add_argument("--theta-batch", type=int, default=1)
+    ap.add_argument("--solver-x", choices=["cg", "lu"], default=None, help="solver of the X update (default: --solver)")
+    ap.add_argument("--solver-theta", choices=["cg", "lu"], default=None,
+                    help="solver of the Theta update on the reduced Gram (default: --solver)")
+    ap.add_argument("--cg-iters-x", type=int, default=None)
+    ap.add_argument("--cg-iters-theta", type=int, default=None)
+    ap.add_argument("--reference-solvers", action="store_true",
+                    help="what hugewiki.cu runs: X by CG with 100 iterations (hugewiki.cu:2569), Theta by the batched LU "
+                         "(hugewiki.cu:2732); the same as --solver-x cg --cg-iters-x 100 --solver-theta lu")
     a = ap.parse_args(argv)
+    if a.reference_solvers:
+        a.solver_x, a.cg_iters_x, a.solver_theta = "cg", 100, "lu"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -94,7 +108,8 @@ def main(argv=None) -> int:
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     try:
-        run(a.split_dir, a.n, a.f, a.lam, a.iters, a.solver, a.cg_iters, a.theta_batch)
+        run(a.split_dir, a.n, a.f, a.lam, a.iters, a.solver, a.cg_iters, a.theta_batch, solver_x=a.solver_x,
+            solver_theta=a.solver_theta, cg_iters_x=a.cg_iters_x, cg_iters_theta=a.cg_iters_theta)
     finally:
         if world > 1:
             dist.destroy_process_group()

@@ -11,16 +11,17 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-# CUMF_ALS_LIB: load another build of the library (kernel experiments, tools/lu_variants.sh)
+# CUMF_ALS_LIB: load another build of the library (kernel experiments; the profiling build libALS_ablate.so)
 LIB_PATH = os.environ.get("CUMF_ALS_LIB") or os.path.join(CSRC, "libALS.so")
 MAIN_PATH = os.path.join(CSRC, "main")
+ABLATE_LIB_PATH = os.path.join(CSRC, "libALS_ablate.so")  # -DCUMF_ABLATE=1 build (tools/gram_pass_alone.py)
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 # every extern "C" symbol declared in include/cumf_als_capi.h
 C_SYMBOLS = [
     "cumf_doALS", "cumf_doALS_ex", "cumf_plan_create", "cumf_plan_destroy", "cumf_plan_info", "cumf_plan_set_gather_rows", "cumf_gram_fast_status",
-    "cumf_fused_available", "cumf_als_update_fused", "cumf_get_hermitian", "cumf_get_hermitian_fp16", "cumf_cg_solve_batched_fp16", "cumf_set_tt_fp16", "cumf_get_tt_fp16", "cumf_cg_solve_batched", "cumf_lu_solve_batched",
-    "cumf_pack_upper", "cumf_unpack_upper", "cumf_sse", "cumf_set_gram_mode", "cumf_get_gram_mode", "cumf_check_gather_table", "cumf_set_kernel_timing", "cumf_set_debug_switches", "cumf_last_kernel_ms", "cumf_rand_init", "cumf_als_version", "cumf_als_arch",
+    "cumf_fused_available", "cumf_als_update_fused", "cumf_get_hermitian", "cumf_get_hermitian_packed", "cumf_get_hermitian_fp16", "cumf_cg_solve_batched_fp16", "cumf_set_tt_fp16", "cumf_get_tt_fp16", "cumf_cg_solve_batched", "cumf_lu_solve_batched",
+    "cumf_pack_upper", "cumf_unpack_upper", "cumf_sse", "cumf_set_gram_mode", "cumf_get_gram_mode", "cumf_check_gather_table", "cumf_set_kernel_timing", "cumf_last_kernel_ms", "cumf_last_kernel_name", "cumf_last_error", "cumf_release_scratch", "cumf_rand_init", "cumf_als_version", "cumf_als_arch",
 ]
 # C++-linkage drop-in symbols (include/als.h, include/cg.h) under the reference's mangled names
 CXX_SYMBOLS = [
@@ -72,6 +73,8 @@ def load():
     lib.cumf_als_update_fused.argtypes = [vp, ip, fp, fp, fp, C.c_int, C.c_float, C.c_int, C.c_int, vp]
     lib.cumf_get_hermitian.restype = C.c_int
     lib.cumf_get_hermitian.argtypes = [vp, ip, fp, fp, fp, fp, C.c_int, C.c_float, vp]
+    lib.cumf_get_hermitian_packed.restype = C.c_int
+    lib.cumf_get_hermitian_packed.argtypes = [vp, ip, fp, fp, fp, fp, C.c_int, C.c_float, vp]
     lib.cumf_get_hermitian_fp16.restype = C.c_int
     lib.cumf_get_hermitian_fp16.argtypes = [vp, ip, fp, fp, vp, fp, C.c_int, C.c_float, vp]
     lib.cumf_cg_solve_batched_fp16.restype = C.c_int
@@ -94,8 +97,13 @@ def load():
     lib.cumf_get_gram_mode.restype = C.c_int
     lib.cumf_check_gather_table.restype = C.c_int
     lib.cumf_check_gather_table.argtypes = [C.c_long, C.c_int, C.c_int, C.c_int]
-    lib.cumf_set_debug_switches.restype = C.c_int
-    lib.cumf_set_debug_switches.argtypes = [C.c_int]
+    if hasattr(lib, "cumf_set_debug_switches"):  # the profiling build only (libALS_ablate.so through CUMF_ALS_LIB)
+        lib.cumf_set_debug_switches.restype = C.c_int
+        lib.cumf_set_debug_switches.argtypes = [C.c_int]
+    lib.cumf_last_kernel_name.restype = C.c_int
+    lib.cumf_last_kernel_name.argtypes = [C.c_char_p, C.c_int]
+    lib.cumf_last_error.restype = C.c_int
+    lib.cumf_release_scratch.restype = C.c_int
     lib.cumf_set_kernel_timing.restype = C.c_int
     lib.cumf_set_kernel_timing.argtypes = [C.c_int]
     lib.cumf_last_kernel_ms.restype = C.c_int

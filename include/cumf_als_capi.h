@@ -78,7 +78,9 @@ int cumf_plan_info(const cumf_plan_t* plan, long info[4]);
  * colidx/val: DEVICE CSR arrays of the whole matrix (indexed by the plan's row
  * pointers); gather: DEVICE factors gathered from (cols x f); update: DEVICE
  * factors being solved (rows x f), read as the CG warm start and overwritten.
- * `gather` must be smaller than 4 GiB (32-bit byte offsets in the gather: 10.7 M rows at f = 100).
+ * The wave kernels (gram modes auto / fast, 16 <= f <= 207) address `gather` with 64-bit lane addresses: no
+ * size limit.  The workgroup kernels (f <= 14, gram mode exact) use 32-bit byte offsets and need a table
+ * below 4 GiB; cumf_check_gather_table tells which applies.
  */
 /* 1 when cumf_als_update_fused can handle (f, solver) in the current gram mode. */
 int cumf_fused_available(int f, int solver);
@@ -97,6 +99,11 @@ int cumf_als_update_fused(const cumf_plan_t* plan, const int* colidx, const floa
  */
 int cumf_get_hermitian(const cumf_plan_t* plan, const int* colidx, const float* val,
                        const float* gather, float* tt, float* rhs, int f, float lambda, void* stream);
+/* The same batch as PACKED upper triangles (row i keeps columns i .. f-1: f (f + 1) / 2 floats per system, the
+ * layout of cumf_pack_upper), written straight from the accumulators: the payload of the multi-GPU partial-Gram
+ * reduction (hugewiki.cu:2703-2717 copies and adds full f x f matrices) without materialising f x f first. */
+int cumf_get_hermitian_packed(const cumf_plan_t* plan, const int* colidx, const float* val,
+                              const float* gather, float* packed, float* rhs, int f, float lambda, void* stream);
 
 /*
  * fp16 storage of the Gram batch for the solver (the reference's compile-time switch CUMF_TT_FP16 /
@@ -185,11 +192,19 @@ int cumf_get_gram_mode(void);
  * for the last half-iteration and returns their durations in milliseconds.
  */
 int cumf_set_kernel_timing(int enable);
-/* Ablation switches of the half-iteration kernels for profiling (also CUMF_ALS_DBG): 0 = production; any
- * other value makes the RESULTS WRONG on purpose: 1 = no solve (the Gram pass alone), 2 = no Gram pass,
- * 8 = every gather hits row 0, 16 = no gather DMA.  bench.py times the Gram pass alone with 1. */
-int cumf_set_debug_switches(int switches);
 int cumf_last_kernel_ms(float* item_kernel_ms, float* reduce_kernel_ms);
+/* Demangled name of the Gram(+solve) kernel the last half-iteration dispatched, as rocprofv3 prints it
+ * (e.g. "cumf::als_wave_kernel<7, 1, 100, 0>"); buf receives a NUL-terminated string ("" before any launch). */
+int cumf_last_kernel_name(char* buf, int cap);
+
+/* Error state of the entry points that return a value instead of a code: cumf_doALS_ex / cumf_doALS / doALS
+ * return NaN and set it when the opt-in gram mode "fast" meets data outside its range (the reference's own
+ * convention -- print and exit, als.h:628-665 -- is kept for HIP failures only).  Reading clears it. */
+enum { CUMF_ERR_FAST_RANGE = 10001 };
+int cumf_last_error(void);
+/* Frees the scratch the library keeps between calls (tile buffers of the f >= 160 LU, pre-split tables of gram
+ * mode "fast"; one per device and stream, grow-only).  doALS calls it before returning. */
+int cumf_release_scratch(void);
 
 /* Library/version probe used by the loaders' "fail loudly" checks. */
 /* Factor initialisation of the reference's hosts: a[k] = scale * ((float)rand() / (float)RAND_MAX)

@@ -42,6 +42,13 @@ class OracleOps:
         tt.copy_(torch.from_numpy(A))
         rhs.copy_(torch.from_numpy(b))
 
+    def get_hermitian_packed(self, plan, colidx, val, gather, lam, packed, rhs):
+        A, b = pyoracle.gram_rhs(plan.rowptr, colidx.numpy(), val.numpy(), gather.numpy(), plan.f, lam,
+                                 plan.row_begin, plan.row_end)
+        iu = np.triu_indices(plan.f)
+        packed.copy_(torch.from_numpy(np.ascontiguousarray(A[:, iu[0], iu[1]])))
+        rhs.copy_(torch.from_numpy(b))
+
     def solve(self, tt, rhs, x, solver, cg_iters):
         f = rhs.shape[-1]
         if solver in ("cg", 0):

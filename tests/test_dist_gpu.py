@@ -123,6 +123,7 @@ def _rccl_worker(port, scheme, solver, d, m, n, f, lam, iters, theta0, q):
                                 theta_batch=3)
         if scheme.startswith("gather"):
             assert eng._px is not None and eng._px.chunks == 4 and not eng._px.staged
+            assert eng._pt is not None and eng._pt.chunks == 4 and not eng._pt.staged   # the 192 MB side is pipelined too
         eng.init_factors(theta0)
         eng.iterate(iters)
         torch.cuda.synchronize()
@@ -178,3 +179,36 @@ def test_pack_unpack_upper(alslib):
         back = torch.zeros_like(a)
         als.unpack_upper(packed, back)
         assert torch.equal(back, a)
+
+
+@pytest.mark.parametrize("args", [["--scheme", "gather"], ["--shape", "hugewiki", "--scheme", "reduce", "--solver", "cg"],
+                                  ["--scheme", "reduce"]])
+def test_bench_world2_branch_runs(alslib, args):
+    """bench.py's `world > 1` branch (process group, from_device_ratings / from_local_slab,
+    barrier, MAX all-reduce of the elapsed time) executed with TWO ranks, launched exactly as the driver launches
+    it (python -m torch.distributed.run ... bench.py --gpus 2) -- on the one GPU of this box, so gloo stands in
+    for RCCL (CUMF_BENCH_BACKEND=gloo: collectives staged through the host) and both ranks share cuda:0.  The
+    shape is shrunk (--scale): the line is checked for shape, not for speed."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from tests.test_dist_cpu import _free_port
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CUMF_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--scale", "0.05", "--no-cpu-baseline"] + args
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]     # rank 0 only
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1
+    assert line["value"] > 0 and np.isfinite(line["value"]) and line["ms_per_step"] > 0
+    assert line["scaling"] == ("weak" if "hugewiki" in args else "strong")

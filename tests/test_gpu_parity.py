@@ -4,8 +4,10 @@ Tolerances (stated per north_star "within a stated fp32 tolerance"):
   * Gram of a whole (unchunked) row, gram mode "exact": BIT-EXACT vs the oracle -- the fp32 MFMA is
     a k-ordered fmaf chain, the same chain a reference thread evaluates (als.h:39-143).
   * Gram, default mode (fp32 split exactly into 3 bf16 terms, 6 products on the bf16 matrix pipe,
-    fp32 accumulate; LU / materialise, f <= 111): max |G - G_fp64| <= 1e-6 * max|G| and no worse
-    than 3x the fmaf chain's own distance from the fp64 Gram (same error class).
+    fp32 accumulate): max |G - G_fp64| <= 1e-6 * max|G| and no worse than 1.5x the fmaf chain's own distance
+    from the fp64 Gram; on adversarial inputs (mixed signs, nine decades, cancelling right-hand sides,
+    near-sub-normal products) bounded PER ENTRY by rho * 2^-24 * sum |theta_i theta_j| with rho <= 3 + n_u / 16
+    and <= max(1.5 x the fmaf chain's rho, 3) (test_split_gram_adversarial_per_entry).
   * Gram of a chunked row: partial chains are summed -> rel 2e-6 of the row's scale.
   * LU solve on identical (A, b): the exact-order variant is bit-exact; the fast
     register-resident symmetric elimination agrees to 2e-5 relative.
@@ -83,8 +85,91 @@ def test_split_gram_error_class(oracle, alslib, f):
                      np.abs(rhs.cpu().numpy() - b64).max() / np.abs(b64).max())
     als.set_gram_mode("auto")
     assert err["auto"][0] <= 1e-6 and err["auto"][1] <= 2e-6, err
-    assert err["auto"][0] <= 3 * err["exact"][0] + 5e-8, err
-    assert err["auto"][1] <= 3 * err["exact"][1] + 5e-8, err
+    assert err["auto"][0] <= 1.5 * err["exact"][0] + 5e-8, err
+    assert err["auto"][1] <= 1.5 * err["exact"][1] + 5e-8, err
+
+
+def _adversarial_table(kind, n, f, rng):
+    """Gather tables that a benign 0.2 * U[0, 1) draw never produces."""
+    if kind == "mixed_sign":          # every off-diagonal Gram entry is a cancelling sum
+        return rng.standard_normal((n, f)).astype(np.float32)
+    if kind == "wide_range":          # nine decades inside every row, mixed signs
+        mag = 10.0 ** rng.uniform(-6.0, 3.0, size=(n, f))
+        return (mag * rng.choice([-1.0, 1.0], size=(n, f))).astype(np.float32)
+    if kind == "cancel_pairs":        # rows 2k and 2k + 1 are theta and -theta + eps: the right-hand side cancels to r * eps
+        base = rng.standard_normal((n // 2, f))
+        t = np.empty((n, f))
+        t[0::2] = base
+        t[1::2] = -base + 1e-4 * rng.standard_normal((n // 2, f))
+        return t.astype(np.float32)
+    if kind == "tiny":                # products of 1e-30: the l terms are still normal numbers
+        return (1e-15 * rng.standard_normal((n, f))).astype(np.float32)
+    if kind == "near_subnormal":      # products of 1e-36: partial products l * h are sub-normal
+        return (1e-18 * rng.standard_normal((n, f))).astype(np.float32)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["mixed_sign", "wide_range", "cancel_pairs", "tiny", "near_subnormal"])
+@pytest.mark.parametrize("f", [30, 100, 110, 200])
+def test_split_gram_adversarial_per_entry(oracle, alslib, kind, f):
+    """VERDICT r02 item 1a.  The default Gram arithmetic (exact bf16x3 split, six products on the bf16 matrix
+    pipe) on inputs chosen to hurt it -- mixed signs (cancelling sums), nine decades of magnitude inside a row,
+    theta / -theta + eps pairs with equal ratings (the RHS cancels), non-integer ratings on a 0..100 scale,
+    values whose partial products approach the fp32 sub-normal range -- bounded PER ENTRY against the fp64 Gram:
+
+        |G_ij - G64_ij| <= rho * 2^-24 * sum_k |theta_ki theta_kj|  (+ n_u * 2^-126: one minimum normal per rating)
+
+    with rho <= 3 + n_u / 16 (two units for the dropped ml + lm + ll terms, six fp32 accumulator roundings per
+    32-rating stage) AND rho no worse than max(1.5 x the rho of the bit-exact fmaf chain, 3): same error class
+    as the reference's arithmetic entry by entry, not relative to max |G|.  Rows of 1, 31, 32, 33 ... 1500 ratings."""
+    _need_gpu()
+    from cumf_als_amd import als
+
+    rng = np.random.RandomState(1000 + f)
+    n = 1600
+    lens = np.array([1, 2, 31, 32, 33, 63, 64, 65, 100, 206, 400, 777, 1500] + list(rng.randint(1, 300, size=35)))
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    table = _adversarial_table(kind, n, f, rng)
+    cols, vals = [], []
+    for k in lens:
+        if kind == "cancel_pairs":   # both members of a pair, with the same rating
+            pairs = rng.choice(n // 2, size=(k + 1) // 2, replace=False)
+            c = np.sort(np.concatenate([2 * pairs, 2 * pairs + 1])[:k])
+            rv = 100.0 * rng.random_sample(n // 2)
+            v = rv[c // 2]
+        else:
+            c = np.sort(rng.choice(n, size=k, replace=False))
+            v = 100.0 * rng.random_sample(k)       # non-integer, 0..100
+        cols.append(c)
+        vals.append(v)
+    indices = np.concatenate(cols).astype(np.int32)
+    data = np.concatenate(vals).astype(np.float32)
+    lam = 0.0   # the regulariser would hide the small entries of the diagonal
+    tt64, b64 = oracle.gram_rhs(indptr, indices, data, table, f, lam, dtype=np.float64)
+    # sum_k |theta_ki| |theta_kj| and sum_k |r_k| |theta_ki|: the same oracle on the absolute values
+    ab64, abb64 = oracle.gram_rhs(indptr, indices, np.abs(data), np.abs(table), f, lam, dtype=np.float64)
+    u = 2.0 ** -24
+    floor = lens.astype(np.float64) * 2.0 ** -126
+    dev = lambda a: torch.from_numpy(a).cuda()
+    plan = als.Plan(indptr, f)
+    assert plan.n_multi_rows == 0
+    rho = {}
+    try:
+        for mode in ("exact", "auto"):
+            als.set_gram_mode(mode)
+            tt, rhs = als.get_hermitian(plan, dev(indices), dev(data), dev(table), lam)
+            torch.cuda.synchronize()
+            eg = np.abs(tt.cpu().numpy().astype(np.float64) - tt64) / (u * ab64 + floor[:, None, None])
+            eb = np.abs(rhs.cpu().numpy().astype(np.float64) - b64) / (u * abb64 + floor[:, None])
+            rho[mode] = (eg.reshape(len(lens), -1).max(1), eb.max(1))
+    finally:
+        als.set_gram_mode("auto")
+    msg = {m: (float(v[0].max()), float(v[1].max())) for m, v in rho.items()}
+    print(f"rho[{kind}, f={f}] (gram, rhs):", msg)
+    bound = 3.0 + lens / 16.0
+    assert (rho["auto"][0] <= bound).all() and (rho["auto"][1] <= bound).all(), msg
+    assert rho["auto"][0].max() <= max(1.5 * rho["exact"][0].max(), 3.0), msg
+    assert rho["auto"][1].max() <= max(1.5 * rho["exact"][1].max(), 3.0), msg
 
 
 @pytest.mark.parametrize("f", [20, 64, 100, 128, 200])
@@ -157,6 +242,86 @@ def test_fast_gram_range_flags(alslib):
             eng.iterate(1)
     finally:
         als.set_gram_mode("auto")
+
+
+def test_fast_gram_tolerates_nan_rows_of_empty_columns(alslib):
+    """rows / columns without ratings get NaN factors by design (0/0 in CG, a zero pivot in LU:
+    cg.cu:128; test_empty_row_gives_nan_like_reference).  Their table rows are never gathered, so gram mode
+    "fast" must run on such a dataset -- sparse id spaces like ML-10M's n = 65 133 -- without raising."""
+    _need_gpu()
+    from cumf_als_amd import als, datagen
+
+    f, m, n = 32, 40, 30
+    rng = np.random.RandomState(5)
+    rows = rng.randint(0, m, 600)
+    cols = rng.randint(0, n - 3, 600)          # columns n-3 .. n-1 have no rating at all
+    keep = np.unique(rows * n + cols)
+    rows, cols = keep // n, keep % n
+    r = datagen.from_coo(m, n, rows, cols, rng.randint(1, 6, len(rows)).astype(np.float32), [0], [0], [1.0]).to("cuda")
+    try:
+        als.set_gram_mode("fast")
+        als.gram_fast_status()
+        eng = als.ALSEngine(r, f, 0.05, solver="lu")
+        eng.init_factors()
+        eng.iterate(3)          # raises on a range flag
+        torch.cuda.synchronize()
+        th = eng.thetaT.cpu().numpy()
+        assert np.isnan(th[n - 3:]).all() and np.isfinite(th[: n - 3]).all() and np.isfinite(eng.XT.cpu().numpy()).all()
+        assert als.gram_fast_status() == 0
+    finally:
+        als.set_gram_mode("auto")
+
+
+def test_packed_gram_equals_pack_of_full(alslib):
+    """cumf_get_hermitian_packed writes the packed upper triangles straight from the accumulators: bit-identical
+    to cumf_get_hermitian + cumf_pack_upper, whole rows and chunked rows, wave and workgroup kernels."""
+    _need_gpu()
+    from cumf_als_amd import als
+
+    r = _dataset(60, 300, 5000, 300, seed=9, row_alpha=1.3)
+    d = r.numpy()
+    rg = r.to("cuda")
+    try:
+        for mode in ("auto", "exact"):
+            als.set_gram_mode(mode)
+            for f, chunk in ((10, 0), (20, 32), (100, 0), (100, 64), (128, 0), (200, 96)):
+                theta = torch.from_numpy(_factors(r.n, f, 2) - 0.1).cuda()
+                plan = als.Plan(d["csr_indptr"], f, chunk=chunk)
+                tt, rhs = als.get_hermitian(plan, rg.csr_indices, rg.csr_data, theta, 0.05)
+                pk, rhs2 = als.get_hermitian_packed(plan, rg.csr_indices, rg.csr_data, theta, 0.05)
+                torch.cuda.synchronize()
+                assert torch.equal(pk, als.pack_upper(tt)), (mode, f, chunk)
+                assert torch.equal(rhs, rhs2), (mode, f, chunk)
+    finally:
+        als.set_gram_mode("auto")
+
+
+def test_dispatched_kernel_name_and_committed_traffic(alslib):
+    """bench.py's roofline.kernel is the symbol that was dispatched (cumf_last_kernel_name), and the committed
+    PMC traffic (profiles/traffic.json) is keyed by that name: the headline kernel must be in it."""
+    _need_gpu()
+    import json
+    import os
+
+    from cumf_als_amd import als
+
+    r = _dataset(64, 80, 2000, 100, seed=3).to("cuda")
+    d = r.numpy()
+    x = torch.zeros((r.m, 100), device="cuda")
+    theta = torch.from_numpy(_factors(r.n, 100, 1)).cuda()
+    als.update_fused(als.Plan(d["csr_indptr"], 100), r.csr_indices, r.csr_data, theta, x, 0.05, "lu", 6)
+    name = als.last_kernel_name()
+    assert name.startswith("cumf::als_wave_kernel<7, 1, 100"), name
+    als.update_fused(als.Plan(d["csr_indptr"], 100), r.csr_indices, r.csr_data, theta, x, 0.05, "cg", 6)
+    assert als.last_kernel_name().startswith("cumf::als_wave_kernel<7, 0, 100"), als.last_kernel_name()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    table = json.load(open(os.path.join(root, "profiles", "traffic.json")))
+    assert any(e["kernel"].replace(" ", "") == name.replace(" ", "") for e in table["kernels"]), \
+        (name, [e["kernel"] for e in table["kernels"]])
+    # the ablation switches are not part of the product library
+    assert not hasattr(alslib, "cumf_set_debug_switches")
+    with pytest.raises(RuntimeError):
+        als.set_debug_switches(1)
 
 
 def test_long_row_many_slots(oracle, alslib):
@@ -294,13 +459,30 @@ def test_fused_half_iteration(oracle, alslib, gram_mode, solver, f):
     x_o = oracle.half_iteration(d["csr_indptr"], d["csr_indices"], d["csr_data"], theta, x0.copy(), f, lam,
                                 solver=solver)
     rg = r.to("cuda")
+    if solver == "cg":
+        A, b = oracle.gram_rhs(d["csr_indptr"], d["csr_indices"], d["csr_data"], theta, f, lam)
+        A64, b64 = A.astype(np.float64), b.astype(np.float64)
+        res_o = np.linalg.norm(np.einsum("bij,bj->bi", A64, x_o.astype(np.float64)) - b64, axis=1)
     for chunk in (0, 64):
         plan = als.Plan(d["csr_indptr"], f, chunk=chunk)
         x = torch.from_numpy(x0.copy()).cuda()
         als.update_fused(plan, rg.csr_indices, rg.csr_data, torch.from_numpy(theta).cuda(), x, lam, solver, 6)
         torch.cuda.synchronize()
-        err = np.abs(x.cpu().numpy() - x_o).max()
-        assert err <= 5e-4 * max(1.0, np.abs(x_o).max()), (chunk, err)
+        xh = x.cpu().numpy()
+        err = np.abs(xh - x_o).max()
+        if solver == "lu":
+            # the elimination is the same factorisation in another rounding order (2e-5 on
+            # identical (A, b)); on top sits the Gram arithmetic of the mode: 1e-4 RELATIVE, no absolute floor
+            assert err <= 1e-4 * np.abs(x_o).max(), (chunk, err, np.abs(x_o).max())
+        else:
+            # CG(6): the tolerance lives on the residual.  After the same <= 6 iterations the HIP
+            # iterate is as good a solution as the oracle's: ||A x - b|| within 1e-4 ||b|| of the oracle's, per
+            # system; residuals below the stopping threshold sqrt(CG_ERROR) = 1e-2 (cg.cu:31,195) are
+            # interchangeable (an iterate that stops one step earlier is still below it)
+            res_h = np.linalg.norm(np.einsum("bij,bj->bi", A64, xh.astype(np.float64)) - b64, axis=1)
+            assert (np.abs(res_h - res_o) <= 1e-4 * np.linalg.norm(b64, axis=1) + 1e-2).all(), \
+                (chunk, np.abs(res_h - res_o).max())
+            assert err <= 5e-4 * max(1.0, np.abs(x_o).max()), (chunk, err)
 
 
 def test_empty_row_gives_nan_like_reference(oracle, alslib):

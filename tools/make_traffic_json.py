@@ -1,11 +1,15 @@
 #!/usr/bin/env python3
-"""profiles/<round>/<tag>/pmc_fetch.txt + pmc_write.txt -> traffic.json: HBM-side bytes per launch of
-the dominant half-iteration kernel, the X-side and Theta-side launches separately.
-bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
-gfx950 (it tallies 128-byte requests at 64 bytes)."""
+"""profiles/<round>/<tag>/pmc_fetch.txt + pmc_write.txt -> one traffic entry (JSON on stdout): HBM-side bytes per
+launch of the dominant half-iteration kernel of that run, the X-side and Theta-side launches separately.
+bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 (it
+tallies 128-byte requests at 64 bytes).  `kernel` is the name as the library reports it (cumf_last_kernel_name:
+rocprofv3's name without the leading "void " and the parameter list) -- bench.py replays an entry only for the
+kernel it dispatched.  tools/merge_traffic.py collects the entries of a round into profiles/traffic.json."""
 import json
 import re
 import sys
+
+GRAM_KERNELS = ("als_wave_kernel", "als_wave_multi_kernel", "als_item_kernel")
 
 
 def parse(path):
@@ -21,19 +25,39 @@ def parse(path):
     return out
 
 
-d = sys.argv[1]
-fetch, write = parse(f"{d}/pmc_fetch.txt"), parse(f"{d}/pmc_write.txt")
-main = [k for k in fetch if "als_wave_kernel" in k[0] or "als_item_kernel" in k[0]]
-main.sort(key=lambda k: k[1])  # the X side has fewer items (rows are chunked) than the Theta side has rows
-res = {"source": f"{d.split('gpurun_out/')[-1]}/pmc_fetch.txt + pmc_write.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
-                 "separate passes, per dispatch; bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB, FETCH_SIZE doubled per the "
-                 "gfx950 note of MI355X_MICROARCH.md)"}
-sides = {}
-for name, k in zip(("x_side", "theta_side"), main[:2]):
-    f_kib, w_kib = fetch[k]["FETCH_SIZE"], write.get(k, {}).get("WRITE_SIZE", 0.0)
-    sides[name] = {"kernel": k[0], "grid": k[1], "fetch_size_kib": f_kib, "write_size_kib": w_kib,
-                   "bytes_per_launch": (2 * f_kib + w_kib) * 1024.0}
-res.update(sides)
-if len(sides) == 2:
-    res["bytes_per_launch"] = 0.5 * (sides["x_side"]["bytes_per_launch"] + sides["theta_side"]["bytes_per_launch"])
-print(json.dumps(res, indent=1))
+def norm(name):
+    return name[5:] if name.startswith("void ") else name
+
+
+def main():
+    d = sys.argv[1]
+    fetch, write = parse(f"{d}/pmc_fetch.txt"), parse(f"{d}/pmc_write.txt")
+    cand = [k for k in fetch if any(g in k[0] for g in GRAM_KERNELS)]
+    if not cand:
+        raise SystemExit(f"{d}: no Gram kernel in pmc_fetch.txt")
+    # the dominant kernel = the Gram kernel with the most fetched bytes over its launches
+    by_name = {}
+    for k in cand:
+        by_name[k[0]] = by_name.get(k[0], 0.0) + fetch[k]["FETCH_SIZE"]
+    name = max(by_name, key=by_name.get)
+    main_keys = sorted((k for k in cand if k[0] == name), key=lambda k: k[1])  # X side: fewer items than Theta has rows
+    tag = d.rstrip("/").split("gpurun_out/")[-1].replace("profiles_", "profiles/")
+    res = {"kernel": norm(name),
+           "source": f"{tag}/pmc_fetch.txt + pmc_write.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, per "
+                     "dispatch; bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB, FETCH_SIZE doubled per the gfx950 note of "
+                     "MI355X_MICROARCH.md)"}
+    sides = {}
+    for side, k in zip(("x_side", "theta_side"), main_keys[:2]):
+        f_kib, w_kib = fetch[k]["FETCH_SIZE"], write.get(k, {}).get("WRITE_SIZE", 0.0)
+        sides[side] = {"kernel": norm(k[0]), "grid": k[1], "fetch_size_kib": f_kib, "write_size_kib": w_kib,
+                       "bytes_per_launch": (2 * f_kib + w_kib) * 1024.0}
+    res.update(sides)
+    if len(sides) == 2:
+        res["bytes_per_launch"] = 0.5 * (sides["x_side"]["bytes_per_launch"] + sides["theta_side"]["bytes_per_launch"])
+    elif sides:
+        res["bytes_per_launch"] = sides["x_side"]["bytes_per_launch"]
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
