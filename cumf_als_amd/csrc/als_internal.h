@@ -78,6 +78,7 @@ struct KernelArgs {
   // dense_slots: item i (wave kernel) / row i (reduce kernel) of this launch uses slot i of `part` and
   // every item is dumped, none solved in place (batched "Gram -> tiles -> solver kernel" path)
   int dense_slots;
+  int whole_only;  // no item of the launch has a slot (the plan has no chunked rows): the LU wave kernel without its dump exit
   long long row_begin;
   int f;
   float lambda;

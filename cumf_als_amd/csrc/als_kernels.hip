@@ -1549,10 +1549,12 @@ hipError_t launch_half_iteration(const KernelArgs& a, int mode, long n_items, lo
     g_timed_item = n_items > 0;
     g_timed_reduce = n_mrows > 0;
     hipError_t e = hipSuccess;
+    KernelArgs aw = a;
+    aw.whole_only = n_mrows == 0;  // no chunked row in the plan: every item is a whole row
     switch (nb_for_f(a.f)) {
 #define CUMF_WAVE(N)                                              \
   case N:                                                         \
-    e = wave_item_launch<N>(a, mode, n_items, stream);            \
+    e = wave_item_launch<N>(aw, mode, n_items, stream);           \
     if (e != hipSuccess) return e;                                \
     if (g_timing) (void)hipEventRecord(g_ev[1], stream);          \
     e = slice_reduce_only<N>(a, mode, n_mrows, stream);           \

@@ -155,6 +155,7 @@ struct WaveGather {
   int dbg;
 #endif
   bool is_feat, is_val;    // last feature block: this lane holds a feature / the rating slot
+  bool has_val;            // is_val and the item has ratings (an empty row reads zeros instead)
 
   __device__ __forceinline__ void init(const KernelArgs& a, int f, long long begin, int len_, int lane) {
     const int c = lane & 15;
@@ -172,8 +173,13 @@ struct WaveGather {
     is_val = fi == f;
     // lanes behind the features re-read the start of the row (in bounds) and drop the value
     last_off = is_feat ? 64 * (NB - 1) : -4 * c;
-    val_base = is_val ? a.val + begin + 8 * g : g_wave_zeros;
-    idx_base = a.colidx + begin + 8 * g;
+    // A row without ratings still runs ONE stage, on zeros (the accumulators then flow from the stage loop into
+    // the solver without a merge with a "no stage" path: that merge cost 41 spilled registers in the LU kernel).
+    // Its index / rating loads must not touch colidx / val (begin may be the end of the arrays): they read the
+    // zero row; "+ 8 g + 1" because the clamped index forms address the item's last rating at base[-1 - 8 g].
+    has_val = is_val && len_ > 0;
+    val_base = has_val ? a.val + begin + 8 * g : g_wave_zeros;
+    idx_base = len_ > 0 ? a.colidx + begin + 8 * g : reinterpret_cast<const int*>(g_wave_zeros) + 8 * g + 1;
   }
 
   template <bool FULL>
@@ -198,7 +204,7 @@ struct WaveGather {
   // the last tile column is sum r * theta = the right-hand side)
   template <bool FULL>
   __device__ __forceinline__ void load_val(WaveStage<NB>& st, int s) const {
-    const float* vp = val_base + (is_val ? kWaveStage * s : 0);
+    const float* vp = val_base + (has_val ? kWaveStage * s : 0);
     if constexpr (FULL) {
       const f32x4u lo = *reinterpret_cast<const f32x4u*>(vp);
       const f32x4u hi = *reinterpret_cast<const f32x4u*>(vp + 4);
@@ -208,7 +214,7 @@ struct WaveGather {
         st.rv[4 + e] = hi[e];
       }
     } else {
-      const int last = is_val ? len - 1 - (kWaveStage * s + 8 * g) : 7;
+      const int last = has_val ? len - 1 - (kWaveStage * s + 8 * g) : 7;
 #pragma unroll
       for (int e = 0; e < 8; ++e) st.rv[e] = vp[e < last ? e : last];
     }
@@ -381,6 +387,24 @@ __device__ __forceinline__ void stage_step(const WaveGather<NB>& wg, Planes<NB, 
                                            int s_idx) {
   // in flight: chunks + ratings of the stage that is multiplied now, indices of stage s_next
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the LDS-DMA chunks have landed
+#if CUMF_WAVE_VARIANT & 64
+  if constexpr (KIND == kStepLast) {
+    // the last stage of an item prefetches nothing, so its LDS buffer need not be freed early: chunk -> registers ->
+    // planes block by block (8 raw registers live instead of 8 NB) -- the register pressure at the hand-over to the
+    // solver is what makes the allocator park accumulator tiles in scratch
+    static_for<NB>([&](auto bc) {
+      constexpr int B = decltype(bc)::value;
+      static_for<8>([&](auto ec) {
+        constexpr int E = decltype(ec)::value;
+        R.raw[B][E] = lds_lane[64 * (E * NB + B)];
+      });
+      if constexpr (B == NB - 1) static_for<8>([&](auto ec) { wg.template finish_one<decltype(ec)::value, ARITH>(R); });
+      static_for<4>([&](auto vc) { split_pair<NB, B, decltype(vc)::value>(R, P); });
+    });
+    static_for<gram_products<ARITH>()>([&](auto pc) { gram_product<NB, decltype(pc)::value>(P, acc); });
+    return;
+  }
+#endif
   wg.dma_read(R, lds_lane);
   static_for<8>([&](auto ec) { wg.template finish_one<decltype(ec)::value, ARITH>(R); });  // consumes R.rv
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the chunks are in registers, the buffer is free
@@ -534,10 +558,12 @@ __device__ __forceinline__ void back_substitute_tiles(const f32x4 (&acc)[NB * (N
     constexpr int Q = kb >> 2;  // pivots of this block live in z[Q]
     if constexpr (Q < NQ) {
       if constexpr (n == 0) issue(std::integral_constant<int, kb>{}, std::integral_constant<int, buf>{});
+#if !(CUMF_WAVE_VARIANT & 256)
       if constexpr (kb > 0) {
         dump(std::integral_constant<int, kb - 1>{});
         issue(std::integral_constant<int, kb - 1>{}, std::integral_constant<int, buf ^ 1>{});
       }
+#endif
       if (16 * kb <= top) {  // uniform: the last block column may hold nothing but y
         static_for<16>([&](auto jc) {
           constexpr int j = 15 - decltype(jc)::value;
@@ -552,6 +578,12 @@ __device__ __forceinline__ void back_substitute_tiles(const f32x4 (&acc)[NB * (N
           }
         });
       }
+#if CUMF_WAVE_VARIANT & 256
+      if constexpr (kb > 0) {  // variant: no look-ahead (one column buffer live)
+        dump(std::integral_constant<int, kb - 1>{});
+        issue(std::integral_constant<int, kb - 1>{}, std::integral_constant<int, buf ^ 1>{});
+      }
+#endif
     }
   });
   static_for<NQ>([&](auto qc) {
@@ -584,6 +616,7 @@ __device__ __forceinline__ void lu_wave(f32x4 (&acc)[NB * (NB + 1) / 2], float* 
   const bool k1 = kk == 1, k2 = kk == 2, k3 = kk == 3;
   auto sel = [](bool p, float a, float b) { return p ? a : b; };  // flat selects: v_cndmask, no branches
   const float e1c = k1 ? 1.0f : 0.f, e2c = k2 ? 1.0f : 0.f, e3c = k3 ? 1.0f : 0.f;  // unit diagonal of E
+#if !(CUMF_WAVE_VARIANT & 128)
   static_for<NB>([&](auto ic) {
     constexpr int t = tile_of<NB>(decltype(ic)::value, decltype(ic)::value);
 #pragma unroll
@@ -592,6 +625,7 @@ __device__ __forceinline__ void lu_wave(f32x4 (&acc)[NB * (NB + 1) / 2], float* 
       acc[t][r] = sel(4 * kk + r == c, d, acc[t][r]);
     }
   });
+#endif
   float* rdiag = T + 16 * NB * kBsPitch;  // pivot reciprocals, then 16 zeros (rows outside a pivot block read these)
   float* zpad = rdiag + ((f + 3) & ~3);
   if (lane < 16) zpad[lane] = 0.f;
@@ -611,6 +645,7 @@ __device__ __forceinline__ void lu_wave(f32x4 (&acc)[NB * (NB + 1) / 2], float* 
         // first: their latency hides behind the pivot chain
         const int src = 4 * (16 * q + c);  // byte address of lane (q, c)
         float R[NB][4];
+#if !(CUMF_WAVE_VARIANT & 32)
         static_for<NB>([&](auto bc) {
           constexpr int b = decltype(bc)::value;
           if constexpr (b >= Ip) {
@@ -619,6 +654,7 @@ __device__ __forceinline__ void lu_wave(f32x4 (&acc)[NB * (NB + 1) / 2], float* 
             for (int r = 0; r < 4; ++r) R[b][r] = bperm(src, acc[t][r]);
           }
         });
+#endif
         // 1. pivot block: rows = registers 0..3 of lane group q, columns = lanes 4 q .. 4 q + 3 of it
         constexpr int l0 = 20 * q;
         const bool v1 = p0 + 1 < f, v2 = p0 + 2 < f, v3 = p0 + 3 < f;
@@ -665,7 +701,14 @@ __device__ __forceinline__ void lu_wave(f32x4 (&acc)[NB * (NB + 1) / 2], float* 
         float ub[NB];
         static_for<NB>([&](auto bc) {
           constexpr int b = decltype(bc)::value;
-          if constexpr (b >= Ip) ub[b] = fmaf(e3c, R[b][3], fmaf(e2, R[b][2], fmaf(e1, R[b][1], e0 * R[b][0])));
+          if constexpr (b >= Ip) {
+#if CUMF_WAVE_VARIANT & 32
+            constexpr int t = tile_of<NB>(Ip, b);  // variant: broadcasts issued block by block (4 live registers, not 4 NB)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) R[b][r] = bperm(src, acc[t][r]);
+#endif
+            ub[b] = fmaf(e3c, R[b][3], fmaf(e2, R[b][2], fmaf(e1, R[b][1], e0 * R[b][0])));
+          }
         });
         // 4. the eliminated rows stay in the accumulators (the update below leaves rows at and above a
         // pivot alone); only the pivot reciprocals go to LDS, for the back substitution
@@ -720,6 +763,33 @@ __device__ __forceinline__ float row16_sum(float v) {  // all-reduce over the 16
   v += dpp_term<0x141, 0xf>(v);  // row_half_mirror
   v += dpp_term<0x140, 0xf>(v);  // row_mirror
   return v;
+}
+
+// Sums of FOUR registers over the 16 lanes of a DPP row, transposed: every lane c ends with the full sum of
+// register c & 3.  11 instructions instead of 4 x row16_sum = 16, and the result is already where the
+// row -> column layout change wants it (lane (g, c) holds row 4 g + (c & 3) of the block).
+//   xor 1: lanes keep the register of their parity and send the other one  (4 selects + 2 adds)
+//   xor 2: the same on the two pair sums                                      (2 selects + 1 add)
+//   the four quads of the row hold the same register in the same position: row_ror 4, row_ror 8 (2 adds)
+__device__ __forceinline__ float row16_sum4_transposed(float r0, float r1, float r2, float r3, bool c1, bool c2) {
+  const float keep01 = c1 ? r1 : r0, send01 = c1 ? r0 : r1;
+  const float keep23 = c1 ? r3 : r2, send23 = c1 ? r2 : r3;
+  const float t01 = keep01 + dpp_term<0xB1, 0xf>(send01);  // quad_perm [1,0,3,2]
+  const float t23 = keep23 + dpp_term<0xB1, 0xf>(send23);
+  const float keep = c2 ? t23 : t01, send = c2 ? t01 : t23;
+  float w = keep + dpp_term<0x4E, 0xf>(send);  // quad_perm [2,3,0,1]
+  w += dpp_term<0x124, 0xf>(w);                // row_ror:4
+  w += dpp_term<0x128, 0xf>(w);                // row_ror:8
+  return w;
+}
+// Two FMAs on a register pair.  NOT v_pk_fma_f32: the packed form (98 of them per CG iteration instead of 196
+// scalar FMAs) returned WRONG mat-vecs on 1-4 % of the long rows of the Netflix X side, a different set of rows in
+// every run, while the partner wave of the SIMD was in its MFMA phase (profiles/r03/pk_fma_bisect.txt: the same
+// source with scalar FMAs is clean, with either row reduction).  No software hazard explains it (even-aligned pairs,
+// counted lgkmcnt, the DPP wait states are there), so packed fp32 arithmetic stays out of kernels that share a SIMD
+// with MFMA work (-fno-slp-vectorize keeps the compiler from forming it on its own).
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) {
+  return f32x2{fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])};
 }
 
 template <int NB, int NW, int W, int I>
@@ -801,44 +871,41 @@ __device__ __forceinline__ void cg_wave_core(f32x4 (&T)[(NB * (NB + 1) / 2 + NW 
     combine(b);
     static_for<NB>([&](auto jc) { b[decltype(jc)::value] = live[decltype(jc)::value] ? b[decltype(jc)::value] : 0.f; });
   }
-  // ---- y = A v
+  // ---- y = A v.  Per tile 4 + 4 FMAs (direct half: rows of the tile against v_J; mirrored half: columns
+  // against v_I in the row layout), per block row ONE transposed 4-register reduction and one ds_bpermute.
+  const bool c1 = (c & 1) != 0, c2 = (c & 2) != 0;
   auto matvec = [&](const float (&v)[NB], float (&y)[NB]) {
-    float ca[NB];
+    f32x2 ca[NB];
     static_for<NB>([&](auto jc) {
-      ca[decltype(jc)::value] = 0.f;
+      ca[decltype(jc)::value] = f32x2{0.f, 0.f};
       y[decltype(jc)::value] = 0.f;
     });
     static_for<NB>([&](auto ic) {
       constexpr int I = decltype(ic)::value;
       if constexpr (cg_row_has_any<NB, NW, W, I>()) {
-        float pr[4] = {0.f, 0.f, 0.f, 0.f};
+        f32x2 pr01 = {0.f, 0.f}, pr23 = {0.f, 0.f};
         if constexpr (cg_row_has_offdiag<NB, NW, W, I>()) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) pr[r] = bperm(row_addr + 4 * r, v[I]);
+          pr01 = f32x2{bperm(row_addr, v[I]), bperm(row_addr + 4, v[I])};
+          pr23 = f32x2{bperm(row_addr + 8, v[I]), bperm(row_addr + 12, v[I])};
         }
-        float ra[4] = {0.f, 0.f, 0.f, 0.f};
+        f32x2 ra01 = {0.f, 0.f}, ra23 = {0.f, 0.f};
         static_for<NB>([&](auto jc) {
           constexpr int J = decltype(jc)::value;
           if constexpr (J >= I && tile_of<NB>(I, J) % NW == W) {
             constexpr int s = tile_of<NB>(I, J) / NW;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ra[r] = fmaf(T[s][r], v[J], ra[r]);
-            if constexpr (J > I) {
-              float t = ca[J];
-#pragma unroll
-              for (int r = 0; r < 4; ++r) t = fmaf(T[s][r], pr[r], t);
-              ca[J] = t;
-            }
+            const f32x2 t01 = __builtin_shufflevector(T[s], T[s], 0, 1), t23 = __builtin_shufflevector(T[s], T[s], 2, 3);
+            const f32x2 vj = {v[J], v[J]};
+            ra01 = fma2(t01, vj, ra01);
+            ra23 = fma2(t23, vj, ra23);
+            if constexpr (J > I) ca[J] = fma2(t23, pr23, fma2(t01, pr01, ca[J]));
           }
         });
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ra[r] = row16_sum(ra[r]);
-        y[I] = to_col(ra);
+        y[I] = bperm(sel_addr, row16_sum4_transposed(ra01[0], ra01[1], ra23[0], ra23[1], c1, c2));
       }
     });
     static_for<NB>([&](auto jc) {
       constexpr int J = decltype(jc)::value;
-      float t = ca[J];
+      float t = ca[J][0] + ca[J][1];
       t += bperm(4 * (lane ^ 16), t);
       t += bperm(4 * (lane ^ 32), t);
       y[J] += t;
@@ -846,10 +913,28 @@ __device__ __forceinline__ void cg_wave_core(f32x4 (&T)[(NB * (NB + 1) / 2 + NW 
     combine(y);
     static_for<NB>([&](auto jc) { y[decltype(jc)::value] = live[decltype(jc)::value] ? y[decltype(jc)::value] : 0.f; });
   };
+  // vector operations on block pairs (see fma2: scalar FMAs); NB odd: the last block alone
+  auto pair = [](const float (&u)[NB], int j) { return f32x2{u[j], u[j + 1]}; };
   auto dot = [&](const float (&u)[NB], const float (&v)[NB]) {
-    float t = 0.f;
-    static_for<NB>([&](auto jc) { t = fmaf(u[decltype(jc)::value], v[decltype(jc)::value], t); });
+    f32x2 t2 = {0.f, 0.f};
+    static_for<NB / 2>([&](auto jc) {
+      constexpr int j = 2 * decltype(jc)::value;
+      t2 = fma2(pair(u, j), pair(v, j), t2);
+    });
+    float t = t2[0] + t2[1];
+    if constexpr (NB & 1) t = fmaf(u[NB - 1], v[NB - 1], t);
     return row16_sum(t);
+  };
+  // y = a * u + y
+  auto axpy = [&](float a, const float (&u)[NB], float (&y)[NB]) {
+    const f32x2 a2 = {a, a};
+    static_for<NB / 2>([&](auto jc) {
+      constexpr int j = 2 * decltype(jc)::value;
+      const f32x2 t = fma2(a2, pair(u, j), pair(y, j));
+      y[j] = t[0];
+      y[j + 1] = t[1];
+    });
+    if constexpr (NB & 1) y[NB - 1] = fmaf(a, u[NB - 1], y[NB - 1]);
   };
   // ---- CG (cg.cu:36-231)
   float* xg = a.update + (size_t)row * f;
@@ -870,19 +955,21 @@ __device__ __forceinline__ void cg_wave_core(f32x4 (&T)[(NB * (NB + 1) / 2 + NW 
     matvec(p, ap);
     const float pap = dot(p, ap);
     const float alpha = rsold / pap;
-    static_for<NB>([&](auto jc) {
-      constexpr int J = decltype(jc)::value;
-      x[J] = fmaf(alpha, p[J], x[J]);
-      r[J] = fmaf(-alpha, ap[J], r[J]);
-    });
+    axpy(alpha, p, x);
+    axpy(-alpha, ap, r);
     const float rsnew = dot(r, r);
     if ((double)rsnew < 1e-4) break;  // CG_ERROR (cg.cu:31,195); uniform: every wave computes the same bits
     const float beta = rsnew / rsold;
     rsold = rsnew;
-    static_for<NB>([&](auto jc) {
-      constexpr int J = decltype(jc)::value;
-      p[J] = fmaf(beta, p[J], r[J]);
+    // p = r + beta p
+    const f32x2 b2 = {beta, beta};
+    static_for<NB / 2>([&](auto jc) {
+      constexpr int j = 2 * decltype(jc)::value;
+      const f32x2 t = fma2(b2, pair(p, j), pair(r, j));
+      p[j] = t[0];
+      p[j + 1] = t[1];
     });
+    if constexpr (NB & 1) p[NB - 1] = fmaf(beta, p[NB - 1], r[NB - 1]);
   }
   if (W == 0 && g == 0) {
     static_for<NB>([&](auto jc) {
@@ -968,7 +1055,11 @@ __device__ __forceinline__ void fast_unscale(f32x4 (&acc)[(NB * (NB + 1) / 2 + N
   if (!(__builtin_fabsf(probe) <= 3.0e38f)) atomicOr(flag, 2);
 }
 
-template <int NB, int MODE, int FC, int ARITH = kArithSplit3>
+// WHOLE: every item of the launch is a whole row (the plan has no chunked rows: the Netflix Theta side, the
+// hugewiki X side).  The kernel then has no "dump the partial tiles" exit between the Gram pass and the solver,
+// and THAT exit is what made the register allocator relocate the accumulator tiles at the hand-over and park
+// five of them in scratch (41 spilled registers, 2.9 GB of scratch writes per Netflix Theta launch; 0 without it).
+template <int NB, int MODE, int FC, int ARITH = kArithSplit3, bool WHOLE = false>
 __global__ __launch_bounds__(64, CUMF_WAVE_MIN_WAVES) void als_wave_kernel(const KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = NB * (NB + 1) / 2;
@@ -977,7 +1068,7 @@ __global__ __launch_bounds__(64, CUMF_WAVE_MIN_WAVES) void als_wave_kernel(const
   const int row = a.item_row[item];
   const long long begin = a.item_begin[item];
   const int len = a.item_len[item];
-  const int slot = a.dense_slots ? item : a.item_slot[item];
+  const int slot = WHOLE ? -1 : (a.dense_slots ? item : a.item_slot[item]);
   const int rowlen = a.item_rowlen[item];
   const int f = FC ? FC : a.f;
   // (A static s_setprio for the wave in the odd hardware slot, meant to break a lockstep of the two waves
@@ -987,14 +1078,14 @@ __global__ __launch_bounds__(64, CUMF_WAVE_MIN_WAVES) void als_wave_kernel(const
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // at least one stage, also for a row without ratings (it gathers the zero row: see WaveGather::init)
+  const int nst = len > 0 ? (len + kWaveStage - 1) / kWaveStage : 1;
+  const int nfull = len / kWaveStage;
 #if CUMF_ABLATE
   // the profiling build only (libALS_ablate.so, -DCUMF_ABLATE=1; results are wrong on purpose): 2 = no Gram pass
-  const int nst = (a.dbg & 2) ? 0 : (len + kWaveStage - 1) / kWaveStage;
-#else
-  const int nst = (len + kWaveStage - 1) / kWaveStage;
+  if (!(a.dbg & 2))
 #endif
-  const int nfull = len / kWaveStage;
-  if (nst > 0) {
+  {
     WaveGather<NB> wg;
     wg.init(a, f, begin, len, lane);
     WaveStage<NB> R;
@@ -1016,9 +1107,11 @@ __global__ __launch_bounds__(64, CUMF_WAVE_MIN_WAVES) void als_wave_kernel(const
   }
   if constexpr (ARITH == kArithFast) fast_unscale<NB, 1, 0>(acc, a.fast_flag);
 
-  if (slot >= 0) {
-    wave_tiles_to_partial<NB>(acc, a.part + (size_t)slot * NT * 256, lane);
-    return;
+  if constexpr (!WHOLE) {
+    if (slot >= 0) {
+      wave_tiles_to_partial<NB>(acc, a.part + (size_t)slot * NT * 256, lane);
+      return;
+    }
   }
   const float reg = (float)rowlen * a.lambda;  // als.cu:547: (end - start) * lambda
 #if CUMF_ABLATE
@@ -1040,6 +1133,11 @@ __global__ __launch_bounds__(64, CUMF_WAVE_MIN_WAVES) void als_wave_kernel(const
   } else if constexpr (MODE == kModeCG) {
     cg_wave_core<NB, 1, 0>(acc, smem, a, f, row, rowlen, lane);  // the reference's default solver (als.cu:28)
   } else {
+#if CUMF_WAVE_VARIANT & 16
+    // every tile in registers at this point: the allocator cannot carry a tile in scratch across the Gram -> LU boundary
+#pragma unroll
+    for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(acc[t]));
+#endif
     lu_wave<NB, FC>(acc, smem, f, reg, a.update + (size_t)row * f, lane);
   }
 }
@@ -1064,8 +1162,8 @@ __device__ __forceinline__ void multi_body(float* smem, const KernelArgs& a, lon
   f32x4 acc[TPW];
 #pragma unroll
   for (int s = 0; s < TPW; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int nst = (len + kWaveStage - 1) / kWaveStage;
-  if (nst > 0) {
+  const int nst = len > 0 ? (len + kWaveStage - 1) / kWaveStage : 1;  // a row without ratings: one stage on zeros
+  {
     WaveGather<NB> wg;
     wg.init(a, f, begin, len, lane);
     WaveStage<NB> R;
@@ -1225,19 +1323,25 @@ hipError_t wave_solve_launch<CUMF_WAVE_NB>(const KernelArgs& a, int mode, long n
 
 #if CUMF_WAVE_PART == 1 && CUMF_WAVE_NB <= 7
 // ---- part 1: the LU form of the wave-per-item kernel
-template <int NB, int FC, int ARITH>
-static hipError_t launch_wave_lu(const KernelArgs& a, long n_items, hipStream_t stream) {
+template <int NB, int FC, int ARITH, bool WHOLE>
+static hipError_t launch_wave_lu_w(const KernelArgs& a, long n_items, hipStream_t stream) {
   const size_t stage_lds = wave_stage_lds_floats<NB>() * sizeof(float);
   const size_t lu_lds = wave_lu_lds_floats<NB>(a.f) * sizeof(float);
   const size_t lds = lu_lds > stage_lds ? lu_lds : stage_lds;
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(als_wave_kernel<NB, kModeLU, FC, ARITH>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(als_wave_kernel<NB, kModeLU, FC, ARITH, WHOLE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  note_item_kernel(reinterpret_cast<const void*>(als_wave_kernel<NB, kModeLU, FC, ARITH>));
-  hipLaunchKernelGGL((als_wave_kernel<NB, kModeLU, FC, ARITH>), dim3((unsigned)n_items), dim3(64), lds, stream, a);
+  note_item_kernel(reinterpret_cast<const void*>(als_wave_kernel<NB, kModeLU, FC, ARITH, WHOLE>));
+  hipLaunchKernelGGL((als_wave_kernel<NB, kModeLU, FC, ARITH, WHOLE>), dim3((unsigned)n_items), dim3(64), lds, stream, a);
   return hipGetLastError();
+}
+template <int NB, int FC, int ARITH>
+static hipError_t launch_wave_lu(const KernelArgs& a, long n_items, hipStream_t stream) {
+  // whole_only: the plan has no chunked rows, no item of this launch dumps partial tiles
+  return (a.whole_only && !a.dense_slots) ? launch_wave_lu_w<NB, FC, ARITH, true>(a, n_items, stream)
+                                           : launch_wave_lu_w<NB, FC, ARITH, false>(a, n_items, stream);
 }
 template <>
 hipError_t wave_lu_launch<CUMF_WAVE_NB>(const KernelArgs& a, long n_items, hipStream_t stream) {

@@ -60,7 +60,7 @@ def _sample_rows(indptr_host, count, rng):
     return np.unique(pick)
 
 
-def _oracle_rows(oracle, indptr, indices, data, gather, warm, rows, f, lam, solver, dtype=np.float32):
+def _oracle_rows(oracle, indptr, indices, data, gather, warm, rows, f, lam, solver, dtype=np.float32, cg_iters=6):
     """The oracle's half-iteration on the sampled rows only: their CSR slices are concatenated into a small
     matrix (the gather table stays whole), warm start = the rows of `warm` (CG: cg.cu:48)."""
     ip = indptr.cpu().numpy().astype(np.int64)
@@ -70,19 +70,44 @@ def _oracle_rows(oracle, indptr, indices, data, gather, warm, rows, f, lam, solv
     sub_idx = indices[sel].cpu().numpy()
     sub_val = data[sel].cpu().numpy()
     x = np.ascontiguousarray(warm[torch.from_numpy(rows).to(warm.device)].cpu().numpy(), np.float32)
-    oracle.half_iteration(sub_ptr, sub_idx, sub_val, gather.cpu().numpy(), x, f, lam, solver=solver, dtype=dtype)
+    oracle.half_iteration(sub_ptr, sub_idx, sub_val, gather.cpu().numpy(), x, f, lam, solver=solver, dtype=dtype,
+                          cg_iters=cg_iters)
     return x, (sub_ptr, sub_idx, sub_val)
 
 
-def _check_rows_against_oracle(oracle, indptr, indices, data, gather, warm, got, rows, f, lam, solver, what):
+def _rel_residuals(sub, gather, xs, f, lam):
+    """||A x - b|| / ||b|| per sampled row for each solution set in `xs`, A and b rebuilt in fp64 from the ratings."""
+    sp, si, sv = sub
+    g64 = gather.double()
+    out = np.zeros((len(xs), len(sp) - 1))
+    for k in range(len(sp) - 1):
+        s, e = int(sp[k]), int(sp[k + 1])
+        th = g64[torch.from_numpy(si[s:e]).long().to(g64.device)]
+        rv = torch.from_numpy(sv[s:e]).double().to(g64.device)
+        A = th.T @ th + lam * (e - s) * torch.eye(f, dtype=torch.float64, device=g64.device)
+        b = th.T @ rv
+        bn = float(b.norm())
+        for j, x in enumerate(xs):
+            out[j, k] = float((A @ torch.from_numpy(x[k]).double().to(A.device) - b).norm()) / bn
+    return out
+
+
+def _check_rows_against_oracle(oracle, indptr, indices, data, gather, warm, got, rows, f, lam, solver, what, cg_iters=6,
+                               strict=False):
     """HIP rows vs the oracle's on the same inputs.
     LU: max |x_hip - x_64| <= max(2e-5, 2 x the fp32 oracle's own distance from the fp64 oracle) of the scale --
         on rows of 10^4 .. 10^5 ratings the reference's sequential fp32 chain is itself 1e-4 off, so the fp64
         evaluation of the same algorithm is the yardstick and the fp32 oracle sets the allowance.
-    CG(6): >= 99 % of the rows within 2e-4 * max(1, |x|) of the fp32 oracle element-wise, and EVERY row as good a
-        solution as the oracle's: ||A x - b|| within 1e-4 ||b|| + 1e-2 of the oracle's residual (1e-2 = the
-        stopping threshold sqrt(CG_ERROR) of cg.cu:31,195; A, b in fp64 from the raw ratings)."""
-    x32, (sp, si, sv) = _oracle_rows(oracle, indptr, indices, data, gather, warm, rows, f, lam, solver)
+    CG, strict (cg_iters <= 3, where the recurrence is still well conditioned in fp32): EVERY row within
+        2e-4 * max(1, |x|) of the fp32 oracle, element-wise.
+    CG(6) = the reference's CG_ITER: on systems the first iterations have already solved to fp32 level the
+        recurrence divides rounding noise by rounding noise and the fp32 ORACLE ITSELF leaves the fp64 oracle by up
+        to 6e-2 (measured on the Netflix-shape Theta side: fp32-vs-fp64 1e-5 after 3 iterations, 4e-2 after 6;
+        SURVEY 7.3-3).  The yardstick is therefore the fp64 oracle and the allowance the fp32 oracle's own spread,
+        as distributions over the sampled rows: median, 99th percentile and maximum of the HIP rows' element-wise
+        distance from the fp64 iterate <= max(2e-4, 2 x the same statistic of the fp32 oracle), and the same for
+        the relative residual ||A x - b|| / ||b|| (floor 1e-4): HIP is as good a CG(6) as the reference's fp32."""
+    x32, sub = _oracle_rows(oracle, indptr, indices, data, gather, warm, rows, f, lam, solver, cg_iters=cg_iters)
     xh = got[torch.from_numpy(rows).to(got.device)].cpu().numpy()
     assert np.array_equal(np.isnan(xh), np.isnan(x32)), what
     if solver == "lu":
@@ -94,23 +119,23 @@ def _check_rows_against_oracle(oracle, indptr, indices, data, gather, warm, got,
               f"hip-vs-oracle32 {np.abs(xh - x32).max() / scale:.3e}")
         assert e_hip <= max(2e-5, 2.0 * e_o32), (what, e_hip, e_o32)
         return
-    el = np.abs(xh - x32).max(1) / np.maximum(1.0, np.abs(x32).max(1))
-    g64 = gather.double()
-    res_h, res_o, bn = [], [], []
-    for k in range(len(rows)):
-        s, e = int(sp[k]), int(sp[k + 1])
-        th = g64[torch.from_numpy(si[s:e]).long().to(g64.device)]
-        rv = torch.from_numpy(sv[s:e]).double().to(g64.device)
-        A = th.T @ th + lam * (e - s) * torch.eye(f, dtype=torch.float64, device=g64.device)
-        b = th.T @ rv
-        res_h.append(float((A @ torch.from_numpy(xh[k]).double().to(A.device) - b).norm()))
-        res_o.append(float((A @ torch.from_numpy(x32[k]).double().to(A.device) - b).norm()))
-        bn.append(float(b.norm()))
-    res_h, res_o, bn = np.array(res_h), np.array(res_o), np.array(bn)
-    print(f"{what}: rows {len(rows)}  element-wise max {el.max():.3e}  within 2e-4: {(el <= 2e-4).mean():.4f}  "
-          f"max |res_hip - res_oracle| / ||b|| {(np.abs(res_h - res_o) / bn).max():.3e}")
-    assert (el <= 2e-4).mean() >= 0.99, (what, el.max(), (el <= 2e-4).mean())
-    assert (np.abs(res_h - res_o) <= 1e-4 * bn + 1e-2).all(), (what, np.abs(res_h - res_o).max())
+    if strict:
+        el = np.abs(xh - x32).max(1) / np.maximum(1.0, np.abs(x32).max(1))
+        print(f"{what} CG({cg_iters}): rows {len(rows)}  hip-vs-oracle32 element-wise max {el.max():.3e}")
+        assert (el <= 2e-4).all(), (what, cg_iters, el.max())
+        return
+    x64, _ = _oracle_rows(oracle, indptr, indices, data, gather, warm, rows, f, lam, solver, dtype=np.float64,
+                          cg_iters=cg_iters)
+    den = np.maximum(1.0, np.abs(x64).max(1))
+    e_h, e_o = np.abs(xh - x64).max(1) / den, np.abs(x32 - x64).max(1) / den
+    res = _rel_residuals(sub, gather, [xh, x32, x64], f, lam)
+    stats = lambda v: (float(np.median(v)), float(np.quantile(v, 0.99)), float(v.max()))
+    print(f"{what} CG({cg_iters}): rows {len(rows)}  |x - x64| (median, q99, max): hip {stats(e_h)}  oracle32 {stats(e_o)}  "
+          f"| rel. residual: hip {stats(res[0])}  oracle32 {stats(res[1])}  oracle64 {stats(res[2])}")
+    for sh, so in zip(stats(e_h), stats(e_o)):
+        assert sh <= max(2e-4, 2.0 * so), (what, stats(e_h), stats(e_o))
+    for sh, so in zip(stats(res[0]), stats(res[1])):
+        assert sh <= max(1e-4, 2.0 * so), (what, stats(res[0]), stats(res[1]))
 
 
 @pytest.mark.parametrize("f,solver", [(100, "cg"), (100, "lu"), (64, "lu"), (64, "cg"), (200, "cg"), (200, "lu")])
@@ -136,6 +161,15 @@ def test_sampled_rows_match_oracle_at_full_size(oracle, alslib, netflix, f, solv
                                solver, f"netflix f={f} {solver} X side")
     cols = _sample_rows(r.csc_indptr.cpu().numpy(), nt, rng)
     warm = eng.thetaT.clone()
+    if solver == "cg":
+        # three iterations first: still deterministic to 1e-5 in fp32, every row must match the fp32 oracle
+        eng.cg_iters = 3
+        eng.update_theta()
+        torch.cuda.synchronize()
+        _check_rows_against_oracle(oracle, r.csc_indptr, r.csc_indices, r.csc_data, eng.XT, warm, eng.thetaT, cols, f,
+                                   LAM, solver, f"netflix f={f} {solver} Theta side", cg_iters=3, strict=True)
+        eng.thetaT.copy_(warm)
+        eng.cg_iters = 6
     eng.update_theta()
     torch.cuda.synchronize()
     _check_rows_against_oracle(oracle, r.csc_indptr, r.csc_indices, r.csc_data, eng.XT, warm, eng.thetaT, cols, f, LAM,

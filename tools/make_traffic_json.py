@@ -35,12 +35,19 @@ def main():
     cand = [k for k in fetch if any(g in k[0] for g in GRAM_KERNELS)]
     if not cand:
         raise SystemExit(f"{d}: no Gram kernel in pmc_fetch.txt")
-    # the dominant kernel = the Gram kernel with the most fetched bytes over its launches
+    # the dominant kernel FAMILY = the Gram kernel with the most fetched bytes over its launches; the two instances of
+    # the wave kernel that differ only in the last template argument (WHOLE: the plan has no chunked rows -- the
+    # Theta side of the Netflix shape -- or it has -- the X side) are one family
+    def family(n):
+        return re.sub(r",\s*(true|false)>$", ">", n)
+
     by_name = {}
     for k in cand:
-        by_name[k[0]] = by_name.get(k[0], 0.0) + fetch[k]["FETCH_SIZE"]
-    name = max(by_name, key=by_name.get)
-    main_keys = sorted((k for k in cand if k[0] == name), key=lambda k: k[1])  # X side: fewer items than Theta has rows
+        by_name[family(k[0])] = by_name.get(family(k[0]), 0.0) + fetch[k]["FETCH_SIZE"]
+    fam = max(by_name, key=by_name.get)
+    main_keys = sorted((k for k in cand if family(k[0]) == fam), key=lambda k: k[1])  # X side: fewer items than Theta has rows
+    main_keys = [main_keys[0], main_keys[-1]] if len(main_keys) > 1 else main_keys
+    name = main_keys[0][0]   # the X-side instance: what bench.py reports as roofline.kernel
     tag = d.rstrip("/").split("gpurun_out/")[-1].replace("profiles_", "profiles/")
     res = {"kernel": norm(name),
            "source": f"{tag}/pmc_fetch.txt + pmc_write.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, per "
