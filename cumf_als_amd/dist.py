@@ -36,17 +36,26 @@ import torch.distributed as dist
 # partitioning (pure functions of the row pointers; covered by CPU tests)
 # ----------------------------------------------------------------------------------------
 
-def balanced_slabs(rowptr: np.ndarray, parts: int) -> np.ndarray:
-    """Cut rows [0, R) into `parts` contiguous slabs of (nearly) equal nnz.
+def solve_row_cost(f: int, solver) -> float:
+    """What one row's SOLVE costs, in ratings of Gram work (measured on MI355X at f = 100: the in-kernel LU of a
+    100 x 100 system takes as long as the Gram pass over ~180 ratings, CG(6) as ~70; LU ~ f^3 against f^2 per
+    rating, CG ~ f^2 against f^2).  Used to balance slabs by cost instead of by ratings alone: on a side with
+    many short rows (the Netflix Theta side: 206 ratings per row) the solves are half of the time."""
+    return 1.8 * f if solver in ("lu", 1) else 70.0
+
+
+def balanced_slabs(rowptr: np.ndarray, parts: int, row_cost: float = 0.0) -> np.ndarray:
+    """Cut rows [0, R) into `parts` contiguous slabs of (nearly) equal cost = ratings + row_cost * rows
+    (row_cost = 0: equal nnz).
 
     Returns `parts + 1` boundaries.  Replaces the hand-written `csc_m[]` /
     dynamic batch queue of hugewiki.cu:2273-2275, 2490-2496 with a static split.
     """
     rowptr = np.asarray(rowptr, dtype=np.int64)
     rows = len(rowptr) - 1
-    total = rowptr[-1] - rowptr[0]
-    targets = rowptr[0] + (total * np.arange(1, parts, dtype=np.float64) / parts)
-    cuts = np.searchsorted(rowptr, targets, side="left")
+    cost = (rowptr - rowptr[0]).astype(np.float64) + float(row_cost) * np.arange(rows + 1, dtype=np.float64)
+    targets = cost[-1] * np.arange(1, parts, dtype=np.float64) / parts
+    cuts = np.searchsorted(cost, targets, side="left")
     bounds = np.concatenate([[0], np.clip(cuts, 0, rows), [rows]]).astype(np.int64)
     return np.maximum.accumulate(bounds)
 
@@ -178,15 +187,15 @@ class SlabGather:
             torch.index_select(self.recv, 0, self.idx, out=out)
 
 
-def pipeline_bounds(rowptr: np.ndarray, slab_bounds: np.ndarray, chunks: int) -> np.ndarray:
-    """Every rank's row slab cut into `chunks` contiguous nnz-balanced pieces: [world, chunks + 1] global row
+def pipeline_bounds(rowptr: np.ndarray, slab_bounds: np.ndarray, chunks: int, row_cost: float = 0.0) -> np.ndarray:
+    """Every rank's row slab cut into `chunks` contiguous cost-balanced pieces: [world, chunks + 1] global row
     ids, computed identically on every rank from the global row pointer."""
     rowptr = np.asarray(rowptr, dtype=np.int64)
     world = len(slab_bounds) - 1
     out = np.zeros((world, chunks + 1), dtype=np.int64)
     for g in range(world):
         a, b = int(slab_bounds[g]), int(slab_bounds[g + 1])
-        out[g] = a + balanced_slabs(rowptr[a:b + 1], chunks)
+        out[g] = a + balanced_slabs(rowptr[a:b + 1], chunks, row_cost)
     return out
 
 
@@ -312,7 +321,7 @@ class DistALS:
         self.thetaT = torch.zeros((self.n, f), dtype=torch.float32, device=dev)
 
         # X side: contiguous nnz-balanced row slabs
-        self.xb = balanced_slabs(mat.csr_indptr, self.world)
+        self.xb = balanced_slabs(mat.csr_indptr, self.world, solve_row_cost(f, self.solver_x))
         x0, x1 = int(self.xb[self.rank]), int(self.xb[self.rank + 1])
         rp, ci, va = slice_csr(mat.csr_indptr, mat.csr_indices, mat.csr_data, x0, x1)
         self.x_rows = x1 - x0
@@ -324,14 +333,15 @@ class DistALS:
 
         if scheme == "gather":
             self.XT = torch.zeros((self.m, f), dtype=torch.float32, device=dev)
-            self.tb = balanced_slabs(mat.csc_indptr, self.world)
+            self.tb = balanced_slabs(mat.csc_indptr, self.world, solve_row_cost(f, self.solver_theta))
             t0, t1 = int(self.tb[self.rank]), int(self.tb[self.rank + 1])
             rp, ci, va = slice_csr(mat.csc_indptr, mat.csc_indices, mat.csc_data, t0, t1)
             self.t_rows = t1 - t0
             self.t_plan = ops.plan(rp, f, chunk)
             self.t_colidx, self.t_val = ops.to_device(ci), ops.to_device(va)
             # the Theta all-gather is the big one (n x f: 192 MB at the Netflix shape): pipelined like X
-            self._t_pipe = self._make_pipeline(mat.csc_indptr, np.asarray(rp), self.tb, chunk)
+            self._t_pipe = self._make_pipeline(mat.csc_indptr, np.asarray(rp), self.tb, chunk,
+                                               solve_row_cost(f, self.solver_theta))
         elif scheme == "reduce":
             # X slab only (device-resident for the whole run); slab-local CSC for the partial Grams
             self.XT = torch.zeros((self.x_rows, f), dtype=torch.float32, device=dev)
@@ -356,7 +366,7 @@ class DistALS:
         self.cg_iters_x = self.cg_iters if cg_iters_x is None else cg_iters_x
         self.cg_iters_theta = self.cg_iters if cg_iters_theta is None else cg_iters_theta
 
-    def _make_pipeline(self, rowptr_global, rowptr_local, bounds, chunk: int):
+    def _make_pipeline(self, rowptr_global, rowptr_local, bounds, chunk: int, row_cost: float = 0.0):
         """One side's update in pieces with the all-gather of each piece under the next one (`PipelinedGather`);
         CUMF_ALS_PIPE_CHUNKS pieces (default 4; 1 = one kernel + one blocking all-gather).  Returns
         (piece bounds [world, chunks + 1], [(lo, hi, plan)] of this rank) or None."""
@@ -366,7 +376,7 @@ class DistALS:
         force = os.environ.get("CUMF_ALS_PIPE_FORCE") == "1"  # tests: the RCCL path with world_size 1
         if chunks <= 1 or not dist.is_initialized() or (self.world <= 1 and not force):
             return None
-        pb = pipeline_bounds(rowptr_global, bounds, chunks)
+        pb = pipeline_bounds(rowptr_global, bounds, chunks, row_cost)
         r0 = int(bounds[self.rank])
         plans = []
         for c in range(chunks):
@@ -375,7 +385,8 @@ class DistALS:
         return (pb, plans)
 
     def _make_x_pipeline(self, rowptr_global, rowptr_local, chunk: int) -> None:
-        self._x_pipe = self._make_pipeline(rowptr_global, rowptr_local, self.xb, chunk)
+        self._x_pipe = self._make_pipeline(rowptr_global, rowptr_local, self.xb, chunk,
+                                           solve_row_cost(self.f, self.solver_x))
 
     def _setup_comm(self) -> None:
         """Persistent communication buffers (nothing is allocated or zero-filled
@@ -430,14 +441,16 @@ class DistALS:
         self.XT = torch.zeros((self.m, f), dtype=torch.float32, device=dev)
         rp = r.csr_indptr.cpu().numpy().astype(np.int64)
         cp = r.csc_indptr.cpu().numpy().astype(np.int64)
-        self.xb, self.tb = balanced_slabs(rp, self.world), balanced_slabs(cp, self.world)
+        self.xb = balanced_slabs(rp, self.world, solve_row_cost(f, self.solver_x))
+        self.tb = balanced_slabs(cp, self.world, solve_row_cost(f, self.solver_theta))
         x0, x1 = int(self.xb[self.rank]), int(self.xb[self.rank + 1])
         t0, t1 = int(self.tb[self.rank]), int(self.tb[self.rank + 1])
         self.x_rows, self.t_rows = x1 - x0, t1 - t0
         self.x_plan = ops.plan(rp[x0:x1 + 1] - rp[x0], f, chunk)
         self.t_plan = ops.plan(cp[t0:t1 + 1] - cp[t0], f, chunk)
         self._make_x_pipeline(rp, rp[x0:x1 + 1] - rp[x0], chunk)
-        self._t_pipe = self._make_pipeline(cp, cp[t0:t1 + 1] - cp[t0], self.tb, chunk)
+        self._t_pipe = self._make_pipeline(cp, cp[t0:t1 + 1] - cp[t0], self.tb, chunk,
+                                           solve_row_cost(f, self.solver_theta))
         self.x_colidx, self.x_val = r.csr_indices[rp[x0]:rp[x1]], r.csr_data[rp[x0]:rp[x1]]
         self.t_colidx, self.t_val = r.csc_indices[cp[t0]:cp[t1]], r.csc_data[cp[t0]:cp[t1]]
         self._setup_comm()

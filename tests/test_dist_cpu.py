@@ -65,6 +65,27 @@ def test_balanced_slabs_and_local_csc():
         assert cols[c] == list(zip(d["csc_indices"][s:e].tolist(), d["csc_data"][s:e].tolist()))
 
 
+def test_cost_balanced_slabs():
+    """Slabs balanced by ratings + solve cost per row: on a side with many short rows the solves are half of the
+    time, so equal-nnz slabs would leave the rank that holds the short rows with twice the work."""
+    from cumf_als_amd import dist as cdist
+
+    # 1000 heavy rows (500 ratings) followed by 100 000 light rows (5 ratings): equal nnz either half
+    lens = np.concatenate([np.full(1000, 500), np.full(100000, 5)])
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    by_nnz = cdist.balanced_slabs(rowptr, 2)
+    assert by_nnz[1] == 1000                                    # half of the ratings, 1 % of the rows
+    w = cdist.solve_row_cost(100, "lu")
+    by_cost = cdist.balanced_slabs(rowptr, 2, w)
+    cost = lambda a, b: (rowptr[b] - rowptr[a]) + w * (b - a)
+    c0, c1 = cost(0, by_cost[1]), cost(by_cost[1], len(lens))
+    assert abs(c0 - c1) <= 0.01 * (c0 + c1) and by_cost[1] > 40000
+    assert cdist.solve_row_cost(100, "lu") > cdist.solve_row_cost(100, "cg") > 0
+    pb = cdist.pipeline_bounds(rowptr, by_cost, 4, w)
+    assert pb.shape == (2, 5) and (np.diff(pb, axis=1) >= 0).all()
+    assert pb[0, 0] == 0 and pb[0, -1] == by_cost[1] == pb[1, 0] and pb[1, -1] == len(lens)
+
+
 @pytest.mark.parametrize("scheme,solver", [("gather", "cg"), ("gather", "lu"), ("reduce", "lu"), ("reduce", "cg")])
 def test_world2_matches_single_process(oracle, scheme, solver):
     from cumf_als_amd import datagen

@@ -1,0 +1,10 @@
+#!/bin/bash
+# A/B of two builds of the library on the same box, alternating: tools/ab_libs.sh "<bench args>" libA libB [reps]
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+ARGS="$1"; A="$2"; B="$3"; N=${4:-3}
+Q="--no-cpu-baseline --no-fast-leg --no-gram-leg --allow-missing-traffic --steps 10 --warmup 2"
+for i in $(seq $N); do
+  for L in "$A" "$B"; do
+    CUMF_ALS_LIB=$R/$L python $R/bench.py $Q $ARGS 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('$L', '$ARGS', 'ms', round(d['ms_per_step'],3), 'x', round(r['x_side_ms'],3), 'theta', round(r['theta_side_ms'],3))"
+  done
+done

@@ -62,7 +62,10 @@ def main():
     if len(sides) == 2:
         res["bytes_per_launch"] = 0.5 * (sides["x_side"]["bytes_per_launch"] + sides["theta_side"]["bytes_per_launch"])
     elif sides:
-        res["bytes_per_launch"] = sides["x_side"]["bytes_per_launch"]
+        # one launch only (the slab mode's partial-Gram kernel: the X side dispatches another kernel family)
+        res["launch"] = sides.pop("x_side")
+        res.pop("x_side", None)
+        res["bytes_per_launch"] = res["launch"]["bytes_per_launch"]
     print(json.dumps(res, indent=1))
 
 
