@@ -308,14 +308,29 @@ int fast_flag_get(int** out) {
   return 0;
 }
 
-// Work lists of the batched path; need_tiles: the dense-slot tile buffer (at most 2 GiB = 74 898 systems at
-// f = 100).  The CG path solves whole rows inside the Gram kernel and needs none.
+// Work lists of the batched path; need_tiles: the dense-slot tile buffer (LU above f = 143, materialise at f >= 112).
+// The CG path solves whole rows inside the Gram kernel and needs none.
 int plan_lists(const cumf_plan_t* p, PlanLists* out, hipStream_t stream, bool need_tiles = true) {
   const size_t tile_bytes = (size_t)p->nb * (p->nb + 1) / 2 * 256 * sizeof(float);
   float* part2 = nullptr;
   long rows = 0;
   if (need_tiles && p->n_witems > 0) {
-    rows = (long)std::min<size_t>((size_t)p->n_witems, ((size_t)2 << 30) / tile_bytes);
+    // Sized for 288 GB of HBM: up to 48 GiB (CUMF_ALS_TILE_BUFFER_GB), never more than half of what is free -- the
+    // Netflix Theta side at f = 200 (480 189 rows x 93 KB = 44.7 GB) then runs as ONE Gram launch + ONE LU launch
+    // instead of 21 pairs of 2 GiB batches, each with its own tail.
+    static const double cap_gb = getenv("CUMF_ALS_TILE_BUFFER_GB") ? atof(getenv("CUMF_ALS_TILE_BUFFER_GB")) : 48.0;
+    size_t cap = (size_t)(cap_gb * (double)(1ull << 30));
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      std::lock_guard<std::mutex> lock(g_scratch_mutex);
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      auto have = g_scratch.find(std::make_tuple(dev, stream, kScratchTiles));
+      const size_t mine = have != g_scratch.end() ? have->second.cap : 0;  // our own buffer counts as available
+      cap = std::min(cap, (free_b + mine) / 2);
+    }
+    if (cap < ((size_t)2 << 30)) cap = (size_t)2 << 30;
+    rows = (long)std::min<size_t>((size_t)p->n_witems, cap / tile_bytes);
     if (rows < 1) rows = 1;
     void* q = nullptr;
     const int rc = scratch_get(stream, kScratchTiles, (size_t)rows * tile_bytes, &q);
@@ -445,8 +460,17 @@ extern "C" int cumf_last_kernel_name(char* buf, int cap) {
   char* dem = abi::__cxa_demangle(mangled, nullptr, nullptr, &status);
   const char* name = (status == 0 && dem) ? dem : mangled;
   size_t len = strlen(name);
-  const char* paren = strchr(name, '(');  // drop the parameter list, and the "void " of a template instance
-  if (paren) len = (size_t)(paren - name);
+  // drop the parameter list -- the first '(' outside the template brackets ("float __vector(4)" is a template
+  // argument of the workgroup kernels) -- and the "void " of a template instance
+  int depth = 0;
+  for (size_t i = 0; name[i]; ++i) {
+    if (name[i] == '<') ++depth;
+    if (name[i] == '>') --depth;
+    if (name[i] == '(' && depth == 0) {
+      len = i;
+      break;
+    }
+  }
   if (strncmp(name, "void ", 5) == 0) {
     name += 5;
     len -= 5;
