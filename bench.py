@@ -250,6 +250,8 @@ def main() -> int:
     ap.add_argument("--solver", default="lu", choices=["lu", "cg"])
     ap.add_argument("--cg-iters", type=int, default=6)
     ap.add_argument("--scheme", default="gather", choices=["gather", "reduce"])
+    ap.add_argument("--theta-batch", type=int, default=0,
+                    help="--shape hugewiki: Theta batches of the reduce scheme (0 = 3 when more than one rank, else 1)")
     ap.add_argument("--no-fast-leg", action="store_true",
                     help="skip the informational legs in the other gram modes (opt-in fast, reference-exact)")
     ap.add_argument("--allow-missing-traffic", action="store_true",
@@ -315,8 +317,11 @@ def main() -> int:
         from cumf_als_amd import dist as cdist
 
         xb = np.arange(world + 1, dtype=np.int64) * r.m
+        # THETA_BATCH = 3 as the reference's hugewiki run (hugewiki.cu:27-41): with more than one rank the
+        # reduce-scatter of batch b runs under the partial-Gram pass of batch b + 1
         eng = cdist.DistALS.from_local_slab(m, n, xb, r.csr_indptr, r.csr_indices, r.csr_data, f, lam,
-                                            cdist.HipOps(dev), solver=a.solver, cg_iters=a.cg_iters)
+                                            cdist.HipOps(dev), solver=a.solver, cg_iters=a.cg_iters,
+                                            theta_batch=a.theta_batch if a.theta_batch > 0 else (3 if world > 1 else 1))
         eng.init_factors(theta0)
 
         def step(timed):
