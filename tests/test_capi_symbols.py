@@ -22,6 +22,19 @@ def test_header_symbols_are_exported(alslib):
     assert alslib.cumf_als_arch() == b"gfx950"
 
 
+def test_name_and_error_probes_without_a_gpu(alslib):
+    """cumf_last_kernel_name / cumf_last_error are plain state probes: before any launch the name is empty and
+    no error is pending (no compute, no GPU needed); the ablation entry point is not part of the product library."""
+    import ctypes as C
+
+    buf = C.create_string_buffer(64)
+    assert alslib.cumf_last_kernel_name(buf, 64) == 0 and buf.value == b""
+    assert alslib.cumf_last_error() == 0
+    assert not hasattr(alslib, "cumf_set_debug_switches")
+    header = open(os.path.join(ROOT, "include", "cumf_als_capi.h")).read()
+    assert "cumf_set_debug_switches" not in header and "CUMF_ALS_DBG" not in header
+
+
 def test_mangled_names_match_the_reference_declarations(tmp_path):
     """The C++ symbols are what a caller compiled against the reference's als.h / cg.h binds."""
     src = tmp_path / "decl.cpp"

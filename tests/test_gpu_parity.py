@@ -252,6 +252,14 @@ def test_fast_gram_range_flags(alslib):
         eng.init_factors(theta)
         with pytest.raises(RuntimeError, match="f16 range"):
             eng.iterate(1)
+        # doALS itself: returns NaN + cumf_last_error() == CUMF_ERR_FAST_RANGE instead of exiting from library code
+        # (ADVICE r02); the Python mirror raises
+        db = bad.numpy()
+        with pytest.raises(RuntimeError, match="f16 range"):
+            als.do_als(db["csr_indptr"], db["csr_indices"], db["csr_data"], db["csc_indices"], db["csc_indptr"],
+                       db["csc_data"], db["coo_row"], db["test_row"], db["test_col"], db["test_data"], r.m, r.n, f,
+                       r.nnz, r.nnz_test, 0.05, 2, 1, 1, 0, solver="lu")
+        assert alslib.cumf_last_error() == 0   # reading cleared it
     finally:
         als.set_gram_mode("auto")
 
@@ -337,6 +345,40 @@ def test_dispatched_kernel_name_and_committed_traffic(alslib):
     assert not hasattr(alslib, "cumf_set_debug_switches")
     with pytest.raises(RuntimeError):
         als.set_debug_switches(1)
+
+
+def test_whole_row_kernel_is_bit_identical_to_the_combined_one(alslib):
+    """The LU wave kernel has two instances: WHOLE (the plan has no chunked row: no partial-tile exit, 0 spills) and
+    the combined one.  The same rows must come out bit for bit from both: a plan of short rows alone (WHOLE) against
+    the same rows in a plan that also holds one row long enough to be chunked."""
+    _need_gpu()
+    from cumf_als_amd import als
+
+    f, lam = 100, 0.05
+    rng = np.random.RandomState(11)
+    n = 3000
+    short = list(rng.randint(1, 400, size=40))
+    theta = torch.from_numpy(_factors(n, f, 3) - 0.08).cuda()
+    out = {}
+    for tag, lens in (("whole", short), ("combined", short + [2500])):
+        indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        r2 = np.random.RandomState(5)   # same draws for the common rows (indices and ratings row by row)
+        cols, vals = [], []
+        for k in lens:
+            cols.append(np.sort(r2.choice(n, size=k, replace=False)))
+            vals.append(r2.randint(1, 6, size=k))
+        indices = np.concatenate(cols).astype(np.int32)
+        data = np.concatenate(vals).astype(np.float32)
+        plan = als.Plan(indptr, f, chunk=512)
+        assert (plan.n_multi_rows == 0) == (tag == "whole")
+        x = torch.zeros((len(lens), f), device="cuda")
+        als.update_fused(plan, torch.from_numpy(indices).cuda(), torch.from_numpy(data).cuda(), theta, x, lam, "lu", 6)
+        torch.cuda.synchronize()
+        name = als.last_kernel_name()
+        assert name.endswith("true>" if tag == "whole" else "false>"), name
+        out[tag] = x[: len(short)].cpu().numpy()
+    # (the column draws of the common rows are identical only if the long row is drawn last: it is)
+    np.testing.assert_array_equal(out["whole"], out["combined"])
 
 
 def test_long_row_many_slots(oracle, alslib):
