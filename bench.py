@@ -367,10 +367,16 @@ def main() -> int:
             # of its row / column slabs: nothing travels through host memory
             eng = cdist.DistALS.from_device_ratings(r, f, lam, cdist.HipOps(dev), solver=a.solver, cg_iters=a.cg_iters)
         else:
-            d = r.numpy()
-            mat = cdist.HostMatrix(m, n, d["csr_indptr"], d["csr_indices"], d["csr_data"], d["csc_indptr"],
-                                   d["csc_indices"], d["csc_data"])
-            eng = cdist.DistALS(mat, f, lam, cdist.HipOps(dev), solver=a.solver, cg_iters=a.cg_iters, scheme=a.scheme)
+            # reduce scheme on a shape whose factors would fit one GPU: every rank keeps zero-copy views of ITS row slab
+            # of the device-resident matrix (only the row pointer visits the host); the slab-local CSC is built on the
+            # device (from_local_slab), as for the hugewiki slabs
+            rp = r.csr_indptr.cpu().numpy().astype(np.int64)
+            xb = cdist.balanced_slabs(rp, world, cdist.solve_row_cost(f, a.solver))
+            x0, x1 = int(xb[rank]), int(xb[rank + 1])
+            rowptr_l = torch.from_numpy(rp[x0:x1 + 1] - rp[x0]).to(dev)
+            eng = cdist.DistALS.from_local_slab(m, n, xb, rowptr_l, r.csr_indices[rp[x0]:rp[x1]], r.csr_data[rp[x0]:rp[x1]],
+                                                f, lam, cdist.HipOps(dev), solver=a.solver, cg_iters=a.cg_iters,
+                                                theta_batch=a.theta_batch if a.theta_batch > 0 else 3)
         eng.init_factors(theta0)
 
         def step(timed):
