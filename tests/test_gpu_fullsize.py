@@ -138,7 +138,8 @@ def _check_rows_against_oracle(oracle, indptr, indices, data, gather, warm, got,
         assert sh <= max(1e-4, 2.0 * so), (what, stats(res[0]), stats(res[1]))
 
 
-@pytest.mark.parametrize("f,solver", [(100, "cg"), (100, "lu"), (64, "lu"), (64, "cg"), (200, "cg"), (200, "lu")])
+@pytest.mark.parametrize("f,solver", [(100, "cg"), (100, "lu"), (64, "lu"), (64, "cg"), (200, "cg"), (200, "lu"),
+                                      (128, "lu"), (128, "cg"), (160, "lu")])
 def test_sampled_rows_match_oracle_at_full_size(oracle, alslib, netflix, f, solver):
     """at the full Netflix shape, > 2 000 sampled X rows and Theta rows (incl. the longest and
     the shortest) of BASELINE.json configs[1] (f = 100, also with the reference's default CG), configs[2] (f = 200,
@@ -152,7 +153,7 @@ def test_sampled_rows_match_oracle_at_full_size(oracle, alslib, netflix, f, solv
     eng.init_factors(theta0)
     eng.iterate(1)
     rng = np.random.RandomState(7)
-    nx, nt = (1000, 2000) if f <= 100 else (300, 1000)
+    nx, nt = (1000, 2000) if f <= 100 else (300, 1000) if f >= 200 else (500, 1500)
     rows = _sample_rows(r.csr_indptr.cpu().numpy(), nx, rng)
     warm = eng.XT.clone()
     eng.update_x()
