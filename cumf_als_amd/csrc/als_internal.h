@@ -119,7 +119,8 @@ enum { kGramAuto = 0, kGramExact = 1, kGramFast = 2 };
 void set_gram_mode(int mode);
 int gram_mode();
 bool wave_path_available(int f, int mode);
-// CG on the wave kernels' Gram: Gram -> tiles (dense slots, batches of <= 2 GiB) -> solver kernel
+// the f >= 112 path: two waves per item form the Gram; whole rows are solved in place (CG always, LU up to NB = 9),
+// larger LUs and the materialising pass go Gram -> tiles (dense slots of the pooled tile buffer) -> reduce kernel
 bool wave_batched_path(int f, int mode);
 // unpack = 0: full (batch x f x f) -> packed (batch x f(f+1)/2); unpack = 1: `full` is the packed input,
 // `packed` receives the mirrored full matrices

@@ -1310,7 +1310,7 @@ hipError_t slice_reduce_only(const KernelArgs& a, int mode, long n_mrows, hipStr
 // als_wave_multi_kernel) and a solver kernel (single-wave LU up to NB = 10, the 4-wave lu_solve_mfma
 // above that, wave-level CG on the tiles) picks them up -- the reference's own data flow ("Gram batch
 // in device memory, separate solver", als.cu:782-831), with tiles instead of full f x f matrices and
-// in batches of <= 2 GiB.
+// in batches of the pooled tile buffer (als_plan.cpp: up to 48 GiB, usually ONE batch).
 template <int NB>
 static hipError_t launch_batched_nb(const KernelArgs& a0, int mode, const PlanLists& L, hipStream_t stream) {
   if constexpr (NB < 2) {

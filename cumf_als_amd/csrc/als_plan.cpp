@@ -263,10 +263,10 @@ extern "C" int cumf_plan_info(const cumf_plan_t* p, long info[4]) {
 
 namespace {
 
-// Scratch that outlives a call: the dense-slot tile buffer of the batched path (<= 2 GiB) and the pre-split
+// Scratch that outlives a call: the dense-slot tile buffer of the batched path (up to 48 GiB) and the pre-split
 // copy of the gather table (gram mode "fast").  Process-wide, grow-only, one buffer per (device, stream, kind):
 // calls on one stream are ordered, so the X_BATCH / THETA_BATCH plans of doALS and the pipeline pieces of
-// DistALS share ONE buffer instead of keeping 2 GiB each.  cumf_release_scratch frees them.
+// DistALS share ONE buffer instead of keeping one each.  cumf_release_scratch frees them.
 enum { kScratchTiles = 0, kScratchWords = 1 };
 struct Scratch {
   void* ptr = nullptr;
