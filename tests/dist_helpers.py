@@ -78,7 +78,8 @@ class OracleOps:
                                   val.numel(), thetaT.shape[-1]))
 
 
-def worker(rank, world, port, scheme, solver, d, m, n, f, lam, iters, theta_batch, theta0, q, ops_kind="oracle"):
+def worker(rank, world, port, scheme, solver, d, m, n, f, lam, iters, theta_batch, theta0, q, ops_kind="oracle",
+           side_solvers=None):
     """Entry point of one rank (spawned): runs DistALS and returns full factors through `q`."""
     import os
 
@@ -97,7 +98,8 @@ def worker(rank, world, port, scheme, solver, d, m, n, f, lam, iters, theta_batc
             ops = OracleOps()
         mat = cdist.HostMatrix(m, n, d["csr_indptr"], d["csr_indices"], d["csr_data"], d["csc_indptr"],
                                d["csc_indices"], d["csc_data"])
-        eng = cdist.DistALS(mat, f, lam, ops, solver=solver, cg_iters=6, scheme=scheme, theta_batch=theta_batch)
+        eng = cdist.DistALS(mat, f, lam, ops, solver=solver, cg_iters=6, scheme=scheme, theta_batch=theta_batch,
+                            **(side_solvers or {}))
         eng.init_factors(theta0)
         eng.iterate(iters)
         x = eng.full_XT().cpu().numpy().copy()

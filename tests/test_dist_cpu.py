@@ -65,6 +65,43 @@ def test_balanced_slabs_and_local_csc():
         assert cols[c] == list(zip(d["csc_indices"][s:e].tolist(), d["csc_data"][s:e].tolist()))
 
 
+@pytest.mark.parametrize("scheme", ["gather", "reduce"])
+def test_world2_per_side_solvers(oracle, scheme):
+    """The reference's hugewiki run solves X by CG and Theta by the batched LU (hugewiki.cu:2569, 2732): per-side solvers of
+    DistALS, two ranks over gloo, against the oracle's half-iterations with the same solver per side."""
+    from cumf_als_amd import datagen
+
+    m, n, f, lam, iters = 60, 50, 10, 0.05, 2
+    r = datagen.synth_ratings(m, n, 2400, 300, seed=11, row_alpha=1.1)
+    d = {k: v for k, v in r.numpy().items()}
+    theta0 = (0.2 * np.random.RandomState(0).random_sample((n, f))).astype(np.float32)
+    th_ref, x_ref = theta0.copy(), np.zeros((m, f), np.float32)
+    for _ in range(iters):
+        oracle.half_iteration(d["csr_indptr"], d["csr_indices"], d["csr_data"], th_ref, x_ref, f, lam, solver="cg", cg_iters=4)
+        oracle.half_iteration(d["csc_indptr"], d["csc_indices"], d["csc_data"], x_ref, th_ref, f, lam, solver="lu")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    side = dict(solver_x="cg", cg_iters_x=4, solver_theta="lu")
+    procs = [ctx.Process(target=dist_helpers.worker,
+                         args=(rk, 2, port, scheme, "cg", d, m, n, f, lam, iters, 2 if scheme == "reduce" else 1, theta0, q,
+                               "oracle", side))
+             for rk in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, th, x in outs:
+        if scheme == "gather":   # every row's arithmetic is unchanged
+            np.testing.assert_array_equal(th, th_ref)
+            np.testing.assert_array_equal(x, x_ref)
+        else:                    # the Gram is summed over two slabs in another order
+            assert np.abs(th - th_ref).max() <= 1e-4 * np.abs(th_ref).max()
+            assert np.abs(x - x_ref).max() <= 1e-3 * np.abs(x_ref).max()
+
+
 def test_cost_balanced_slabs():
     """Slabs balanced by ratings + solve cost per row: on a side with many short rows the solves are half of the
     time, so equal-nnz slabs would leave the rank that holds the short rows with twice the work."""
