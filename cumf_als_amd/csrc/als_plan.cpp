@@ -58,12 +58,10 @@ struct cumf_plan {
 namespace {
 
 int default_chunk(int f, long long nnz) {
-  // A chunk of C ratings costs ~C/4 * TPW MFMAs of 32 cycles per wave; 2048 ratings at
-  // f = 100 is ~55 us per workgroup -- small against a half-iteration, large against
-  // the 28 KiB partial-tile write + reduce it causes.  Bigger chunks are cheaper (Netflix X side,
-  // 1 GPU: 2048 -> 4096 saves 0.3 ms of 12) as long as every workgroup slot of the device still
-  // gets ~16 items to balance the tail: 2048 .. 4096 depending on the ratings of this plan (a
-  // 1/8 slab of Netflix on 8 GPUs stays at 2048).  Must be a multiple of kStage.
+  // A chunk of a split row costs a 28 KiB partial-tile write + its share of the reduce (f = 100), so bigger chunks
+  // are cheaper as long as every wave slot of the device still gets >= 12 items to balance the tail: 2048 .. 8192
+  // ratings depending on the ratings of this side (a 1/8 slab of Netflix on 8 GPUs stays at 2048).  Must be a
+  // multiple of kStage.
   (void)f;
   const char* e = getenv("CUMF_ALS_CHUNK");
   int c;
@@ -125,8 +123,7 @@ extern "C" int cumf_plan_create(cumf_plan_t** out, const void* rowptr_host, int 
       fprintf(stderr, "cumf_plan_create: row %ld has invalid length %lld\n", u, len);
       return (int)hipErrorInvalidValue;
     }
-    static const int all_slots = getenv("CUMF_ALS_ALLSLOTS") ? atoi(getenv("CUMF_ALS_ALLSLOTS")) : 0;  // experiment
-    if (len <= chunk && !all_slots) {
+    if (len <= chunk) {
       item_row.push_back((int)u);
       item_begin.push_back(s);
       item_len.push_back((int)len);
@@ -684,4 +681,54 @@ void updateXWithCGHost(float* A, float* x, float* b, const int batchSize, const 
     fprintf(stderr, "updateXWithCGHost failed: %s\n", hipGetErrorString(rc ? (hipError_t)rc : e));
     exit(EXIT_FAILURE);
   }
+}
+
+// C++-linkage drop-in of the reference's fused Gram + CG host (cg.h:34-36, cg.cu:1190-1197; disabled at its only
+// call site, als.cu:809-812: "performance not good").  DEVICE pointers, synchronous.  For the rows
+// batch_offset .. m - 1 of the CSR matrix: A = sum theta theta^T + lambda * n_row * I over the row's columns
+// (cg.cu:735-840), then cgIter warm-started CG steps on A x = ythetaT with x = XT (cg.cu:826-1186).  XT and
+// ythetaT are BATCH-LOCAL: system b (row batch_offset + b) uses XT[b * F ...] and ythetaT[b * F ...].  (The
+// reference kernel strides ythetaT by blockDim.x = 64 instead of F, cg.cu:941 -- a defect of the disabled
+// code path that is not reproduced -- and hard-codes F = 100 in its loader; any f the library supports works
+// here.)  The ratings themselves are not an argument (the right-hand side comes precomputed), so the Gram
+// batch is formed with the materialising kernels, at most 4 GiB at a time, and handed to the batched CG.
+void alsUpdateFeature100Host(const int batch_offset, const int* csrRowIndex, const int* csrColIndex,
+                             const float lambda, const int m, const int F, const float* thetaT, float* XT,
+                             float* ythetaT, int cgIter) {
+  auto fail = [](const char* what, int code) {
+    fprintf(stderr, "alsUpdateFeature100Host failed (%s): %s\n", what, hipGetErrorString((hipError_t)code));
+    exit(EXIT_FAILURE);
+  };
+  if (batch_offset < 0 || m < 0 || !csrRowIndex || !csrColIndex || !thetaT || !XT || !ythetaT)
+    fail("arguments", (int)hipErrorInvalidValue);
+  const long rows = (long)m - batch_offset;
+  if (rows <= 0) return;
+  std::vector<int> rowptr((size_t)m + 1);
+  hipError_t e = hipMemcpy(rowptr.data(), csrRowIndex, rowptr.size() * sizeof(int), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) fail("row pointer", (int)e);
+  const long long nnz = rowptr[(size_t)m];
+  // the rating slot of the gathered rows (the fused right-hand side) reads zeros: this entry point has no ratings
+  float* zeros = nullptr;
+  if ((e = hipMalloc(reinterpret_cast<void**>(&zeros), (size_t)std::max<long long>(nnz, 1) * sizeof(float))) != hipSuccess)
+    fail("rating stand-in", (int)e);
+  if ((e = hipMemset(zeros, 0, (size_t)std::max<long long>(nnz, 1) * sizeof(float))) != hipSuccess) fail("memset", (int)e);
+  const size_t sys_bytes = (size_t)F * F * sizeof(float);
+  const long per_batch = std::max<long>(1, (long)(((size_t)4 << 30) / sys_bytes));
+  float* tt = nullptr;
+  if ((e = hipMalloc(reinterpret_cast<void**>(&tt), (size_t)std::min(rows, per_batch) * sys_bytes)) != hipSuccess)
+    fail("Gram batch", (int)e);
+  for (long b0 = 0; b0 < rows; b0 += per_batch) {
+    const long nb = std::min(per_batch, rows - b0);
+    cumf_plan_t* plan = nullptr;
+    int rc = cumf_plan_create(&plan, rowptr.data(), 0, m, batch_offset + b0, batch_offset + b0 + nb, F, 0);
+    if (rc) fail("plan", rc);
+    rc = cumf_get_hermitian(plan, csrColIndex, zeros, thetaT, tt, nullptr, F, lambda, nullptr);
+    if (rc) fail("Gram", rc);
+    rc = cumf_cg_solve_batched(tt, XT + (size_t)b0 * F, ythetaT + (size_t)b0 * F, nb, F, cgIter, nullptr);
+    if (rc) fail("CG", rc);
+    if ((e = hipDeviceSynchronize()) != hipSuccess) fail("kernels", (int)e);
+    cumf_plan_destroy(plan);
+  }
+  (void)hipFree(tt);
+  (void)hipFree(zeros);
 }

@@ -61,7 +61,7 @@ typedef __attribute__((address_space(3))) float* lds_float_ptr;  // LDS pointer 
 #error "compile with -DCUMF_WAVE_NB=<feature blocks>"
 #endif
 #ifndef CUMF_WAVE_VARIANT
-#define CUMF_WAVE_VARIANT 0  // experiment switches (tools/wave_variants.sh)
+#define CUMF_WAVE_VARIANT 0  // A/B switches (tools/wave_variants.sh): 1 = LU without the per-panel scheduling barrier, 2 = no f == 100 instance, 8 = one wave per SIMD
 #endif
 
 constexpr int kWaveStage = 32;   // ratings per stage = K of v_mfma_f32_16x16x32_bf16
@@ -387,24 +387,6 @@ __device__ __forceinline__ void stage_step(const WaveGather<NB>& wg, Planes<NB, 
                                            int s_idx) {
   // in flight: chunks + ratings of the stage that is multiplied now, indices of stage s_next
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the LDS-DMA chunks have landed
-#if CUMF_WAVE_VARIANT & 64
-  if constexpr (KIND == kStepLast) {
-    // the last stage of an item prefetches nothing, so its LDS buffer need not be freed early: chunk -> registers ->
-    // planes block by block (8 raw registers live instead of 8 NB) -- the register pressure at the hand-over to the
-    // solver is what makes the allocator park accumulator tiles in scratch
-    static_for<NB>([&](auto bc) {
-      constexpr int B = decltype(bc)::value;
-      static_for<8>([&](auto ec) {
-        constexpr int E = decltype(ec)::value;
-        R.raw[B][E] = lds_lane[64 * (E * NB + B)];
-      });
-      if constexpr (B == NB - 1) static_for<8>([&](auto ec) { wg.template finish_one<decltype(ec)::value, ARITH>(R); });
-      static_for<4>([&](auto vc) { split_pair<NB, B, decltype(vc)::value>(R, P); });
-    });
-    static_for<gram_products<ARITH>()>([&](auto pc) { gram_product<NB, decltype(pc)::value>(P, acc); });
-    return;
-  }
-#endif
   wg.dma_read(R, lds_lane);
   static_for<8>([&](auto ec) { wg.template finish_one<decltype(ec)::value, ARITH>(R); });  // consumes R.rv
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the chunks are in registers, the buffer is free
@@ -558,12 +540,10 @@ __device__ __forceinline__ void back_substitute_tiles(const f32x4 (&acc)[NB * (N
     constexpr int Q = kb >> 2;  // pivots of this block live in z[Q]
     if constexpr (Q < NQ) {
       if constexpr (n == 0) issue(std::integral_constant<int, kb>{}, std::integral_constant<int, buf>{});
-#if !(CUMF_WAVE_VARIANT & 256)
       if constexpr (kb > 0) {
         dump(std::integral_constant<int, kb - 1>{});
         issue(std::integral_constant<int, kb - 1>{}, std::integral_constant<int, buf ^ 1>{});
       }
-#endif
       if (16 * kb <= top) {  // uniform: the last block column may hold nothing but y
         static_for<16>([&](auto jc) {
           constexpr int j = 15 - decltype(jc)::value;
@@ -578,12 +558,6 @@ __device__ __forceinline__ void back_substitute_tiles(const f32x4 (&acc)[NB * (N
           }
         });
       }
-#if CUMF_WAVE_VARIANT & 256
-      if constexpr (kb > 0) {  // variant: no look-ahead (one column buffer live)
-        dump(std::integral_constant<int, kb - 1>{});
-        issue(std::integral_constant<int, kb - 1>{}, std::integral_constant<int, buf ^ 1>{});
-      }
-#endif
     }
   });
   static_for<NQ>([&](auto qc) {
@@ -616,7 +590,6 @@ __device__ __forceinline__ void lu_wave(f32x4 (&acc)[NB * (NB + 1) / 2], float* 
   const bool k1 = kk == 1, k2 = kk == 2, k3 = kk == 3;
   auto sel = [](bool p, float a, float b) { return p ? a : b; };  // flat selects: v_cndmask, no branches
   const float e1c = k1 ? 1.0f : 0.f, e2c = k2 ? 1.0f : 0.f, e3c = k3 ? 1.0f : 0.f;  // unit diagonal of E
-#if !(CUMF_WAVE_VARIANT & 128)
   static_for<NB>([&](auto ic) {
     constexpr int t = tile_of<NB>(decltype(ic)::value, decltype(ic)::value);
 #pragma unroll
@@ -625,7 +598,6 @@ __device__ __forceinline__ void lu_wave(f32x4 (&acc)[NB * (NB + 1) / 2], float* 
       acc[t][r] = sel(4 * kk + r == c, d, acc[t][r]);
     }
   });
-#endif
   float* rdiag = T + 16 * NB * kBsPitch;  // pivot reciprocals, then 16 zeros (rows outside a pivot block read these)
   float* zpad = rdiag + ((f + 3) & ~3);
   if (lane < 16) zpad[lane] = 0.f;
@@ -645,7 +617,6 @@ __device__ __forceinline__ void lu_wave(f32x4 (&acc)[NB * (NB + 1) / 2], float* 
         // first: their latency hides behind the pivot chain
         const int src = 4 * (16 * q + c);  // byte address of lane (q, c)
         float R[NB][4];
-#if !(CUMF_WAVE_VARIANT & 32)
         static_for<NB>([&](auto bc) {
           constexpr int b = decltype(bc)::value;
           if constexpr (b >= Ip) {
@@ -654,7 +625,6 @@ __device__ __forceinline__ void lu_wave(f32x4 (&acc)[NB * (NB + 1) / 2], float* 
             for (int r = 0; r < 4; ++r) R[b][r] = bperm(src, acc[t][r]);
           }
         });
-#endif
         // 1. pivot block: rows = registers 0..3 of lane group q, columns = lanes 4 q .. 4 q + 3 of it
         constexpr int l0 = 20 * q;
         const bool v1 = p0 + 1 < f, v2 = p0 + 2 < f, v3 = p0 + 3 < f;
@@ -702,11 +672,6 @@ __device__ __forceinline__ void lu_wave(f32x4 (&acc)[NB * (NB + 1) / 2], float* 
         static_for<NB>([&](auto bc) {
           constexpr int b = decltype(bc)::value;
           if constexpr (b >= Ip) {
-#if CUMF_WAVE_VARIANT & 32
-            constexpr int t = tile_of<NB>(Ip, b);  // variant: broadcasts issued block by block (4 live registers, not 4 NB)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) R[b][r] = bperm(src, acc[t][r]);
-#endif
             ub[b] = fmaf(e3c, R[b][3], fmaf(e2, R[b][2], fmaf(e1, R[b][1], e0 * R[b][0])));
           }
         });
@@ -1133,11 +1098,6 @@ __global__ __launch_bounds__(64, CUMF_WAVE_MIN_WAVES) void als_wave_kernel(const
   } else if constexpr (MODE == kModeCG) {
     cg_wave_core<NB, 1, 0>(acc, smem, a, f, row, rowlen, lane);  // the reference's default solver (als.cu:28)
   } else {
-#if CUMF_WAVE_VARIANT & 16
-    // every tile in registers at this point: the allocator cannot carry a tile in scratch across the Gram -> LU boundary
-#pragma unroll
-    for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(acc[t]));
-#endif
     lu_wave<NB, FC>(acc, smem, f, reg, a.update + (size_t)row * f, lane);
   }
 }
@@ -1318,7 +1278,7 @@ hipError_t wave_solve_launch<CUMF_WAVE_NB>(const KernelArgs& a, int mode, long n
 #endif  // CUMF_WAVE_PART == 0
 
 #ifndef CUMF_WAVE_VARIANT
-#define CUMF_WAVE_VARIANT 0  // experiment switches (tools/wave_variants.sh)
+#define CUMF_WAVE_VARIANT 0  // A/B switches (tools/wave_variants.sh): 1 = LU without the per-panel scheduling barrier, 2 = no f == 100 instance, 8 = one wave per SIMD
 #endif
 
 #if CUMF_WAVE_PART == 1 && CUMF_WAVE_NB <= 7

@@ -28,6 +28,7 @@ CXX_SYMBOLS = [
     "_Z5doALSPKiS0_PKfS0_S0_S2_S0_PfS3_S0_S0_S2_iiillfiiii",
     "_Z17updateXWithCGHostPfS_S_iif",
     "_Z25updateXWithCGHost_tt_fp16PfS_S_iif",
+    "_Z23alsUpdateFeature100HostiPKiS0_fiiPKfPfS3_i",
 ]
 
 _lib = None

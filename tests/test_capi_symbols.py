@@ -39,7 +39,8 @@ def test_mangled_names_match_the_reference_declarations(tmp_path):
     """The C++ symbols are what a caller compiled against the reference's als.h / cg.h binds."""
     src = tmp_path / "decl.cpp"
     src.write_text('#include "als.h"\n#include "cg.h"\n'
-                   "void* a = (void*)&doALS; void* b = (void*)&updateXWithCGHost; void* c = (void*)&updateXWithCGHost_tt_fp16;\n")
+                   "void* a = (void*)&doALS; void* b = (void*)&updateXWithCGHost; void* c = (void*)&updateXWithCGHost_tt_fp16;\n"
+                   "void* d = (void*)&alsUpdateFeature100Host;\n")
     obj = tmp_path / "decl.o"
     subprocess.run(["g++", "-c", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(obj)], check=True)
     syms = subprocess.run(["nm", "-u", str(obj)], capture_output=True, text=True, check=True).stdout

@@ -501,6 +501,58 @@ def test_cg_solve(oracle, alslib, f):
     assert (np.abs(res_h - res_o) <= 1e-4 * np.linalg.norm(b64, axis=1)).all(), np.abs(res_h - res_o).max()
 
 
+@pytest.mark.parametrize("f", [100, 20])
+def test_reference_cxx_entry_points(oracle, alslib, f):
+    """The C++-linkage symbols a caller compiled against the reference's cg.h binds, called as that caller would
+    (device pointers, synchronous): updateXWithCGHost (cg.h:30), updateXWithCGHost_tt_fp16 (cg.h:32) and the fused
+    Gram + CG host alsUpdateFeature100Host (cg.h:34-36) with a batch offset."""
+    _need_gpu()
+    import ctypes as C
+
+    from cumf_als_amd import als
+
+    r = _dataset(64, 90, 2500, 300, seed=16)
+    d = r.numpy()
+    theta = _factors(r.n, f, 4)
+    lam = 0.05
+    A, b = oracle.gram_rhs(d["csr_indptr"], d["csr_indices"], d["csr_data"], theta, f, lam)
+    x0 = _factors(r.m, f, 9) * 0.1
+    x_o = oracle.cg(A, x0, b, f, 6)
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+
+    cg = getattr(alslib, "_Z17updateXWithCGHostPfS_S_iif")
+    cg.restype = None
+    cg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]
+    Ad, bd = torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda()
+    x = torch.from_numpy(x0.copy()).cuda()
+    cg(ptr(Ad), ptr(x), ptr(bd), r.m, f, 6.0)   # synchronous: no torch.cuda.synchronize() before the read
+    assert np.abs(x.cpu().numpy() - x_o).max() <= 2e-4 * max(1.0, np.abs(x_o).max())
+
+    cg16 = getattr(alslib, "_Z25updateXWithCGHost_tt_fp16PfS_S_iif")
+    cg16.restype = None
+    cg16.argtypes = cg.argtypes
+    A16 = A.astype(np.float16)
+    x16_o = oracle.cg(A16.astype(np.float32), x0, b, f, 6)
+    x = torch.from_numpy(x0.copy()).cuda()
+    cg16(ptr(torch.from_numpy(A16).cuda()), ptr(x), ptr(bd), r.m, f, 6.0)
+    assert np.abs(x.cpu().numpy() - x16_o).max() <= 2e-4 * max(1.0, np.abs(x16_o).max())
+
+    fused = getattr(alslib, "_Z23alsUpdateFeature100HostiPKiS0_fiiPKfPfS3_i")
+    fused.restype = None
+    fused.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                      C.c_int]
+    off = 5
+    rg = r.to("cuda")
+    rowptr = torch.from_numpy(d["csr_indptr"].astype(np.int32)).cuda()
+    # batch-local XT / ythetaT: system k is row off + k
+    x = torch.from_numpy(x0[off:].copy()).cuda()
+    y = torch.from_numpy(b[off:].copy()).cuda()
+    fused(off, ptr(rowptr), ptr(rg.csr_indices), lam, r.m, f, ptr(torch.from_numpy(theta).cuda()), ptr(x), ptr(y), 6)
+    err = np.abs(x.cpu().numpy() - x_o[off:]).max()
+    assert err <= 2e-4 * max(1.0, np.abs(x_o).max()), err
+    assert als.last_kernel_name() != ""
+
+
 @pytest.mark.parametrize("gram_mode", ["exact", "auto", "fast"], indirect=True)
 @pytest.mark.parametrize("solver,f", [("cg", 10), ("cg", 100), ("cg", 128), ("lu", 10), ("lu", 100), ("lu", 128),
                                       ("lu", 200), ("lu", 98), ("lu", 110), ("lu", 96), ("lu", 206), ("cg", 98)])
