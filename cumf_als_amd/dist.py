@@ -367,12 +367,20 @@ class DistALS:
         self.cg_iters_theta = self.cg_iters if cg_iters_theta is None else cg_iters_theta
 
     def _make_pipeline(self, rowptr_global, rowptr_local, bounds, chunk: int, row_cost: float = 0.0):
-        """One side's update in pieces with the all-gather of each piece under the next one (`PipelinedGather`);
-        CUMF_ALS_PIPE_CHUNKS pieces (default 4; 1 = one kernel + one blocking all-gather).  Returns
-        (piece bounds [world, chunks + 1], [(lo, hi, plan)] of this rank) or None."""
+        """One side's update in pieces with the all-gather of each piece under the next one (`PipelinedGather`).
+        Pieces: CUMF_ALS_PIPE_CHUNKS if set (1 = one kernel + one blocking all-gather); otherwise 4 when the
+        gathered factor matrix is large enough for its all-gather to matter (>= 32 MB: the Netflix Theta side,
+        192 MB) and 1 when it is not (the Netflix X side, 7 MB = tens of microseconds over xGMI: cutting a 1/8
+        slab's few thousand work items into four launches would only leave wave slots empty in each of them).
+        Returns (piece bounds [world, chunks + 1], [(lo, hi, plan)] of this rank) or None."""
         import os
 
-        chunks = int(os.environ.get("CUMF_ALS_PIPE_CHUNKS", "4"))
+        env = os.environ.get("CUMF_ALS_PIPE_CHUNKS")
+        if env is not None:
+            chunks = int(env)
+        else:
+            gathered_bytes = (len(rowptr_global) - 1) * self.f * 4
+            chunks = 4 if gathered_bytes >= (32 << 20) else 1
         force = os.environ.get("CUMF_ALS_PIPE_FORCE") == "1"  # tests: the RCCL path with world_size 1
         if chunks <= 1 or not dist.is_initialized() or (self.world <= 1 and not force):
             return None

@@ -220,8 +220,9 @@ def test_pipeline_bounds_and_row_map():
 
 
 def test_world2_pipelined_gather_equals_blocking(monkeypatch):
-    """gather scheme, 2 ranks: the pipelined X all-gather (default, 4 pieces) and the blocking one
-    (CUMF_ALS_PIPE_CHUNKS=1) give bit-identical factors."""
+    """gather scheme, 2 ranks: the pipelined all-gathers (4 pieces per side: what the default picks for a factor
+    matrix >= 32 MB) and the blocking ones (CUMF_ALS_PIPE_CHUNKS=1: the default below that) give bit-identical
+    factors."""
     import numpy as np
 
     from cumf_als_amd import datagen
@@ -237,3 +238,26 @@ def test_world2_pipelined_gather_equals_blocking(monkeypatch):
     for a, b in zip(res["4"], res["1"]):
         np.testing.assert_array_equal(a[1], b[1])
         np.testing.assert_array_equal(a[2], b[2])
+
+
+def test_default_pipeline_pieces_follow_the_gathered_bytes(monkeypatch):
+    """Without CUMF_ALS_PIPE_CHUNKS a side is cut into 4 pieces only when its gathered factor matrix is >= 32 MB
+    (Netflix f = 100: Theta 192 MB yes, X 7 MB no)."""
+    import numpy as np
+
+    from cumf_als_amd import dist as cdist
+
+    monkeypatch.delenv("CUMF_ALS_PIPE_CHUNKS", raising=False)
+    monkeypatch.setenv("CUMF_ALS_PIPE_FORCE", "1")
+
+    class _Ops:
+        def plan(self, rowptr, f, chunk=0, row_begin=0, row_end=None):
+            return (row_begin, row_end)
+
+    eng = cdist.DistALS.__new__(cdist.DistALS)
+    eng.f, eng.world, eng.rank, eng.ops = 100, 1, 0, _Ops()
+    monkeypatch.setattr(cdist.dist, "is_initialized", lambda: True)
+    for rows, want in ((17770, None), (480189, 4)):
+        rowptr = np.arange(rows + 1, dtype=np.int64) * 3
+        pipe = eng._make_pipeline(rowptr, rowptr, np.array([0, rows]), 0)
+        assert (pipe is None) if want is None else (pipe[0].shape == (1, want + 1)), rows

@@ -104,7 +104,8 @@ def _rccl_worker(port, scheme, solver, d, m, n, f, lam, iters, theta0, q):
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    os.environ["CUMF_ALS_PIPE_FORCE"] = "1"  # the pipelined (async) all-gather of the X update, on one rank
+    os.environ["CUMF_ALS_PIPE_FORCE"] = "1"  # the pipelined (async) all-gathers, on one rank ...
+    os.environ["CUMF_ALS_PIPE_CHUNKS"] = "4"  # ... and on both sides (the default pipelines only factor matrices >= 32 MB)
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
