@@ -20,8 +20,9 @@ __global__ __launch_bounds__(64) void k(float* out, long long* cycles, int rep) 
   for (int r = 0; r < rep; ++r) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      if (KIND == 0) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, b8, acc[t], 0, 0, 0);
-      if (KIND == 1) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a4, b4, acc[t], 0, 0, 0);
+      // inline asm with VGPR accumulators: the builtins make the compiler shuffle AGPR copies and s_nops into the loop
+      if (KIND == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(a8), "v"(b8));
+      if (KIND == 1) asm volatile("v_mfma_f32_16x16x16_bf16 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(a4), "v"(b4));
     }
   }
   const long long t1 = __builtin_readcyclecounter();
@@ -37,7 +38,7 @@ int main() {
   hipMalloc((void**)&out, 4096 * 64 * 4);
   hipMalloc((void**)&cyc, 4096 * 8);
   const int rep = 2000;
-  for (int blocks : {1, 1024, 2048}) {
+  for (int blocks : {1, 1024, 2048, 4096, 8192}) {
     for (int kind = 0; kind < 2; ++kind) {
       hipEvent_t e0, e1;
       hipEventCreate(&e0);
