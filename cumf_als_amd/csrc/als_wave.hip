@@ -153,6 +153,7 @@ struct WaveGather {
   int g, len;
 #if CUMF_ABLATE
   int dbg;
+  unsigned idx_mask;
 #endif
   bool is_feat, is_val;    // last feature block: this lane holds a feature / the rating slot
   bool has_val;            // is_val and the item has ratings (an empty row reads zeros instead)
@@ -165,6 +166,9 @@ struct WaveGather {
 #if CUMF_ABLATE
     if (a.dbg & 8) row_bytes = 0u;  // ablation: every gather hits row 0
     dbg = a.dbg;
+    // ablation: the gathers keep their shape (four 64-byte row segments per instruction) but only touch the first
+    // 64 / 4096 / 65536 rows of the table (L1- / L2- / MALL-resident at f = 100): profiles/r03/gather_ablation.txt
+    idx_mask = (a.dbg & 32) ? 63u : (a.dbg & 64) ? 4095u : (a.dbg & 128) ? 65535u : 0xffffffffu;
 #endif
     lane_base = reinterpret_cast<const char*>(a.gather) + 4 * c;
     zero_base = reinterpret_cast<const char*>(g_wave_zeros) + 4 * c;
@@ -223,7 +227,11 @@ struct WaveGather {
   // row pointer (+ 4 c) of rating e of stage s, from st.idx
   template <bool FULL, int E>
   __device__ __forceinline__ const char* row_ptr(const WaveStage<NB>& st, int s) const {
+#if CUMF_ABLATE
+    const char* row = lane_base + (unsigned long long)((unsigned)st.idx[E] & idx_mask) * row_bytes;
+#else
     const char* row = lane_base + (unsigned long long)(unsigned)st.idx[E] * row_bytes;  // v_mad_u64_u32
+#endif
     if constexpr (!FULL) {
       const int left = len - (kWaveStage * s + 8 * g);  // ratings of the item from this lane group's first on
       const char* z = zero_base;

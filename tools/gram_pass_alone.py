@@ -33,6 +33,9 @@ def main() -> int:
     ap.add_argument("--solver", default="lu", choices=["lu", "cg"])
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--switches", type=int, default=0,
+                    help="further ablation switches OR-ed to 1 (no solve): 8 = every gather hits row 0, 16 = no gather "
+                         "DMA, 32 / 64 / 128 = gathers confined to the first 64 / 4096 / 65536 table rows")
     a = ap.parse_args()
     shp = datagen.SHAPES[a.shape]
     s, f, lam = a.scale, a.f, shp["lam"]
@@ -52,7 +55,7 @@ def main() -> int:
     eng.solver = a.solver
     keep_x, keep_t = eng.XT.clone(), eng.thetaT.clone()
     g_ms = []
-    als.set_debug_switches(1)  # no solve
+    als.set_debug_switches(1 | a.switches)  # no solve (+ the requested gather ablations)
     als.set_kernel_timing(True)
     names = {}
     for _ in range(a.reps + 1):
@@ -71,7 +74,8 @@ def main() -> int:
     gb_x = 4.0 * f * nnz + 8.0 * nnz + 4.0 * (m + 1)  # Gram + RHS inputs only (no factor write)
     gb_t = 4.0 * f * nnz + 8.0 * nnz + 4.0 * (n + 1)
     print(json.dumps({
-        "library": os.path.basename(os.environ.get("CUMF_ALS_LIB", "libALS.so")), "kernel_x": names["x"],
+        "library": os.path.basename(os.environ.get("CUMF_ALS_LIB", "libALS.so")), "switches": 1 | a.switches,
+        "kernel_x": names["x"],
         "kernel_theta": names["theta"], "x_side_ms": gx, "theta_side_ms": gt,
         "x_side_alg_bytes": gb_x, "theta_side_alg_bytes": gb_t,
         "x_side_frac_of_hbm_roof": gb_x / (gx * 1e-3) / 1e9 / HBM_PEAK_GBS,
