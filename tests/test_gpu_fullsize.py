@@ -352,3 +352,57 @@ def test_normal_equations_other_configs(alslib, netflix, f, solver, tol):
     cols = np.concatenate([rng.choice(r.n, 20, replace=False), np.argsort(clens)[-2:], np.argsort(clens)[:2]])
     assert _residuals(r.csc_indptr, r.csc_indices, r.csc_data, eng.XT, eng.thetaT, cols, LAM) <= tol
     assert torch.isfinite(eng.XT).all() and torch.isfinite(eng.thetaT).all()
+
+
+def test_more_than_2_31_ratings_on_one_gpu(oracle):
+    """64-bit offsets end to end: a CSR matrix with 2.25e9 ratings (> 2^31; the reference's own hugewiki run has
+    3.1e9 and reads its row pointer as uint32, hugewiki.cu:1973) on ONE GPU -- 64-bit row pointer into the plan,
+    item offsets beyond 2^31 in the kernels' index / rating / LDS-DMA addresses -- against the oracle on the first
+    and the last rows (the last ones start at offsets > 2^31), LU and CG.  f = 32 keeps it to a few seconds."""
+    _need_gpu()
+    from cumf_als_amd import als
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60 * (1 << 30):
+        pytest.fail(f"needs 60 GB of device memory (MI355X: 288 GB), {free >> 30} GB free")
+    f, lam = 32, 0.05
+    m, per_row, n = 37500, 60000, 100000          # 2.25e9 ratings, rows of 60 000 (eight 8 192-rating chunks each)
+    nnz = m * per_row
+    assert nnz > 2 ** 31
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    colidx = torch.empty(nnz, dtype=torch.int32, device="cuda")
+    val = torch.empty(nnz, dtype=torch.float32, device="cuda")
+    step = 1 << 28
+    for s in range(0, nnz, step):                 # in pieces: no 18 GB int64 temporary
+        e = min(nnz, s + step)
+        colidx[s:e] = torch.randint(0, n, (e - s,), generator=g, device="cuda", dtype=torch.int32)
+        val[s:e] = torch.randint(1, 6, (e - s,), generator=g, device="cuda", dtype=torch.int32).float()
+    rowptr = np.arange(m + 1, dtype=np.int64) * per_row
+    theta = torch.from_numpy((0.2 * np.random.RandomState(1).random_sample((n, f))).astype(np.float32)).cuda()
+    rows = np.concatenate([np.arange(4), np.arange(m - 4, m)])
+    assert rowptr[rows[-1]] > 2 ** 31
+    plan = als.Plan(rowptr, f)
+    assert plan.n_multi_rows == m
+    for solver in ("lu", "cg"):
+        x = torch.zeros((m, f), dtype=torch.float32, device="cuda")
+        als.update_fused(plan, colidx, val, theta, x, lam, solver, 6)
+        torch.cuda.synchronize()
+        sub_ptr = (np.arange(len(rows) + 1, dtype=np.int64) * per_row).astype(np.int32)
+        sel = [slice(int(rowptr[u]), int(rowptr[u + 1])) for u in rows]
+        sub_idx = torch.cat([colidx[s_] for s_ in sel]).cpu().numpy()
+        sub_val = torch.cat([val[s_] for s_ in sel]).cpu().numpy()
+        ref = np.zeros((len(rows), f), np.float32)  # fp64 arithmetic inside, fp32 factors out (as the bench's fp64 leg)
+        oracle.half_iteration(sub_ptr, sub_idx, sub_val, theta.cpu().numpy(), ref, f, lam, solver=solver,
+                              dtype=np.float64, cg_iters=6)
+        got = x[torch.from_numpy(rows).cuda()].cpu().numpy()
+        assert np.isfinite(got).all()
+        # rows of 60 000 ratings: the fp64 evaluation of the same algorithm is the yardstick (see
+        # _check_rows_against_oracle); LU 2e-5, CG(6) from a zero start 2e-4 of the scale
+        tol = 2e-5 if solver == "lu" else 2e-4
+        assert np.abs(got - ref).max() <= tol * np.abs(ref).max(), (solver, np.abs(got - ref).max(), np.abs(ref).max())
+    # every row of the launch was written (nothing left at its zero start) and rows in the middle solve their system
+    mid = np.array([m // 2, m // 2 + 1])
+    res = _residuals(torch.from_numpy(rowptr), colidx, val, theta, x, mid, lam)
+    assert res <= 5e-2, res
+    assert bool((x.abs().sum(dim=1) > 0).all())
