@@ -47,6 +47,7 @@ T* to_device(const T* host, size_t count) {
 struct Side {
   // one side of the factorisation: rows x cols CSR (CSC of R passed as CSR of R^T, als.cu:867-869)
   const int* rowptr_host;
+  const long long* rowptr64;  // the same widened to 64 bits when nnz > 2^31 - 1 (else nullptr)
   const int* d_colidx;
   const float* d_val;
   long rows;
@@ -61,7 +62,8 @@ void make_side(Side& s, int f, long gather_rows) {
     const long bs = (b != s.nbatch - 1) ? s.rows / s.nbatch : s.rows - (long)b * (s.rows / s.nbatch);
     const long off = (long)b * (s.rows / s.nbatch);
     cumf_plan_t* p = nullptr;
-    DRV_CHECK(cumf_plan_create(&p, s.rowptr_host, 0, s.rows, off, off + bs, f, 0));
+    DRV_CHECK(s.rowptr64 ? cumf_plan_create(&p, s.rowptr64, 1, s.rows, off, off + bs, f, 0)
+                         : cumf_plan_create(&p, s.rowptr_host, 0, s.rows, off, off + bs, f, 0));
     DRV_CHECK(cumf_plan_set_gather_rows(p, gather_rows));  // gram mode "fast" pre-splits the gather table
     s.plans.push_back(p);
     s.offset.push_back(off);
@@ -77,6 +79,24 @@ int env_int(const char* name, int dflt) {
 int g_tt_fp16 = -1;  // fp16 Gram storage for the CG solver: `#define CUMF_TT_FP16` / CUMF_XX_FP16 (als.cu:25-33)
 
 }  // namespace
+
+extern "C" int cumf_widen_rowptr(const int* rowptr32, long rows, long nnz, long long* out64) {
+  if (!rowptr32 || !out64 || rows < 0) return (int)hipErrorInvalidValue;
+  long long hi = 0;
+  unsigned prev = static_cast<unsigned>(rowptr32[0]);
+  out64[0] = prev;
+  for (long i = 1; i <= rows; ++i) {
+    const unsigned cur = static_cast<unsigned>(rowptr32[i]);
+    if (cur < prev) hi += 1ll << 32;  // non-decreasing row pointers: a smaller value is a wrap
+    out64[i] = hi + cur;
+    prev = cur;
+  }
+  if (out64[rows] != (long long)nnz) {
+    fprintf(stderr, "cumf_widen_rowptr: the row pointer ends at %lld, not at nnz = %ld\n", out64[rows], nnz);
+    return (int)hipErrorInvalidValue;
+  }
+  return 0;
+}
 
 extern "C" int cumf_set_tt_fp16(int enable) {
   g_tt_fp16 = enable != 0;
@@ -123,8 +143,16 @@ extern "C" float cumf_doALS_ex(const int* csrRowIndexHostPtr, const int* csrColI
   float* XT = to_device(XTHost, (size_t)m * f);
   double* d_sse = to_device<double>(nullptr, 2);
 
-  Side sx{csrRowIndexHostPtr, csrColIndex, csrVal, m, X_BATCH, {}, {}, {}};
-  Side st{cscColIndexHostPtr, cscRowIndex, cscVal, n, THETA_BATCH, {}, {}, {}};
+  // 2^31 or more ratings: the 4-byte row pointers have wrapped (hugewiki.cu:1973 reads them as unsigned)
+  std::vector<long long> csr64, csc64;
+  if (nnz > 0x7fffffffL) {
+    csr64.resize((size_t)m + 1);
+    csc64.resize((size_t)n + 1);
+    DRV_CHECK(cumf_widen_rowptr(csrRowIndexHostPtr, m, nnz, csr64.data()));
+    DRV_CHECK(cumf_widen_rowptr(cscColIndexHostPtr, n, nnz, csc64.data()));
+  }
+  Side sx{csrRowIndexHostPtr, csr64.empty() ? nullptr : csr64.data(), csrColIndex, csrVal, m, X_BATCH, {}, {}, {}};
+  Side st{cscColIndexHostPtr, csc64.empty() ? nullptr : csc64.data(), cscRowIndex, cscVal, n, THETA_BATCH, {}, {}, {}};
   make_side(sx, f, n);  // X rows gather from thetaT (n rows)
   make_side(st, f, m);  // Theta rows gather from XT (m rows)
 

@@ -206,6 +206,13 @@ int cumf_last_error(void);
  * mode "fast"; one per device and stream, grow-only).  doALS calls it before returning. */
 int cumf_release_scratch(void);
 
+/* Row pointers of a matrix with 2^31 or more ratings handed over as 4-byte values (doALS takes `const int*`; the
+ * reference's own 3.1 G-rating run reads its row-pointer files as unsigned, hugewiki.cu:1973,1984): rowptr32 is read
+ * as uint32 and 2^32 is added at every wrap (row pointers are non-decreasing), out64[0 .. rows] receives the result.
+ * Host pointers.  Returns 0, or hipErrorInvalidValue when the result does not end at nnz.  cumf_doALS_ex does this
+ * itself when nnz > 2^31 - 1. */
+int cumf_widen_rowptr(const int* rowptr32, long rows, long nnz, long long* out64);
+
 /* Library/version probe used by the loaders' "fail loudly" checks. */
 /* Factor initialisation of the reference's hosts: a[k] = scale * ((float)rand() / (float)RAND_MAX)
  * for k in order, libc rand() (main.cpp:72-76 with scale 0.2 after srand(0); als_tf.cc:121-123

@@ -73,3 +73,21 @@ def test_product_never_touches_the_oracle():
                     if re.search(r"(import|include|from|CDLL).*oracle", text):
                         bad.append(os.path.join(base, fn))
     assert not bad, bad
+
+
+def test_widen_rowptr_unwraps_4_byte_row_pointers(alslib):
+    """doALS takes `const int*` row pointers; with 2^31 or more ratings they have wrapped (the reference reads its
+    3.1 G-rating files as unsigned, hugewiki.cu:1973).  cumf_widen_rowptr restores them (host only, no GPU)."""
+    import ctypes as C
+
+    import numpy as np
+
+    lens = np.array([5, 0, 2 ** 31 - 7, 3, 2 ** 31 - 1, 2 ** 30, 9, 0, 2 ** 31 - 1], dtype=np.int64)
+    true = np.concatenate([[0], np.cumsum(lens)])
+    wrapped = (true & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
+    assert (wrapped < 0).any() and true[-1] > 2 ** 32   # negative values and more than one wrap
+    out = np.zeros(len(true), np.int64)
+    rc = alslib.cumf_widen_rowptr(wrapped.ctypes.data_as(C.c_void_p), len(lens), int(true[-1]), out.ctypes.data_as(C.c_void_p))
+    assert rc == 0 and np.array_equal(out, true)
+    rc = alslib.cumf_widen_rowptr(wrapped.ctypes.data_as(C.c_void_p), len(lens), int(true[-1]) + 1, out.ctypes.data_as(C.c_void_p))
+    assert rc != 0   # does not end at nnz
