@@ -358,6 +358,21 @@ def last_kernel_ms():
     return a.value, b.value
 
 
+def kernel_ms_since_reset():
+    """(item_kernel_ms, reduce_kernel_ms, launches) summed over every half-iteration launch sequence since the
+    previous call (cumf_kernel_ms_since_reset): a half-iteration made of several launches is read with one call."""
+    a, b, n = C.c_float(), C.c_float(), C.c_int()
+    _libmod.check(_libmod.load().cumf_kernel_ms_since_reset(C.byref(a), C.byref(b), C.byref(n)),
+                  "cumf_kernel_ms_since_reset")
+    return a.value, b.value, n.value
+
+
+def release_scratch() -> None:
+    """Free the pooled scratch of the CURRENT device (tile buffers of the f >= 144 LU path, pre-split tables of gram
+    mode "fast"): cumf_release_scratch.  ALSEngine.close() / DistALS.close() call it."""
+    _libmod.check(_libmod.load().cumf_release_scratch(), "cumf_release_scratch")
+
+
 class ALSEngine:
     """A dataset resident in HBM + the two half-iteration plans (single GPU).
 
@@ -442,3 +457,11 @@ class ALSEngine:
             self.update_x()
             self.update_theta()
         check_gram_fast()
+
+    def close(self) -> None:
+        """Destroy the plans and hand the library's pooled scratch of this device back (up to 48 GiB of tile buffer
+        at f >= 144 that lives outside torch's caching allocator)."""
+        for p in self.x_plans + self.t_plans:
+            p.close()
+        self.x_plans, self.t_plans = [], []
+        release_scratch()

@@ -131,6 +131,8 @@ void set_kernel_timing(bool on);
 void note_item_kernel(const void* host_function);  // called by the launchers of the Gram(+solve) kernels
 const void* last_item_kernel();
 hipError_t last_kernel_ms(float* item_ms, float* reduce_ms);
+// sums over every timed launch sequence since the previous call (or since timing was switched on), then resets
+hipError_t kernel_ms_since_reset(float* item_ms, float* reduce_ms, int* launches);
 hipError_t launch_sse(const float* val, const int* row, const int* col, const float* thetaT, const float* XT,
                       long count, int f, int surpass_nan, double* out, hipStream_t stream);
 

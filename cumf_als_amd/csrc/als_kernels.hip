@@ -23,10 +23,13 @@
 //     same sequential FMA chain one reference thread computes (als.h:39-143).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 #include <utility>
+#include <vector>
 
 #include "als_internal.h"
 #include "als_device.h"
@@ -1152,16 +1155,47 @@ extern bool g_timing;
 extern hipEvent_t g_ev[3];
 extern bool g_timed_item, g_timed_reduce;
 #endif
+// Every timed launch sequence starts with timing_begin(): it takes the next event triple of a pool (so that the
+// launches of a half-iteration made of several -- X_BATCH / THETA_BATCH plans, the pipeline pieces of the multi-GPU
+// gather scheme -- can be summed afterwards, kernel_ms_since_reset) and leaves it in g_ev.
+void timing_begin();
 
 #if CUMF_SLICE_COMMON
 // the Gram(+solve) kernel the last half-iteration dispatched (bench.py reads its name for roofline.kernel)
-static const void* g_last_item_kernel = nullptr;
-void note_item_kernel(const void* host_function) { g_last_item_kernel = host_function; }
-const void* last_item_kernel() { return g_last_item_kernel; }
+static std::atomic<const void*> g_last_item_kernel{nullptr};
+void note_item_kernel(const void* host_function) { g_last_item_kernel.store(host_function, std::memory_order_relaxed); }
+const void* last_item_kernel() { return g_last_item_kernel.load(std::memory_order_relaxed); }
+namespace {
+struct TimedLaunch {
+  hipEvent_t ev[3];
+  bool item, reduce;
+};
+constexpr size_t kTimedPool = 1024;
+std::vector<TimedLaunch> g_timed;  // pool of event triples, created on first use
+size_t g_timed_used = 0;           // launches since the last reset (the newest one is g_timed[g_timed_used - 1])
+std::mutex g_timed_mutex;
+}  // namespace
 void set_kernel_timing(bool on) {
+  std::lock_guard<std::mutex> lock(g_timed_mutex);
   g_timing = on;
-  if (on && g_ev[0] == nullptr)
-    for (auto& e : g_ev) (void)hipEventCreate(&e);
+  if (on && g_timed.empty()) {
+    g_timed.resize(kTimedPool);
+    for (auto& t : g_timed) {
+      for (auto& e : t.ev) (void)hipEventCreate(&e);
+      t.item = t.reduce = false;
+    }
+  }
+}
+void timing_begin() {
+  if (!g_timing) return;
+  std::lock_guard<std::mutex> lock(g_timed_mutex);
+  if (g_timed_used > 0) {  // the flags of the previous launch are final now
+    g_timed[g_timed_used - 1].item = g_timed_item;
+    g_timed[g_timed_used - 1].reduce = g_timed_reduce;
+  }
+  if (g_timed_used == kTimedPool) g_timed_used = 0;  // nobody read for 1024 launches: start over
+  TimedLaunch& t = g_timed[g_timed_used++];
+  for (int i = 0; i < 3; ++i) g_ev[i] = t.ev[i];
 }
 hipError_t last_kernel_ms(float* item_ms, float* reduce_ms) {
   *item_ms = 0.f;
@@ -1171,6 +1205,26 @@ hipError_t last_kernel_ms(float* item_ms, float* reduce_ms) {
   if (e != hipSuccess) return e;
   if (g_timed_item) (void)hipEventElapsedTime(item_ms, g_ev[0], g_ev[1]);
   if (g_timed_reduce) (void)hipEventElapsedTime(reduce_ms, g_ev[1], g_ev[2]);
+  return hipSuccess;
+}
+hipError_t kernel_ms_since_reset(float* item_ms, float* reduce_ms, int* launches) {
+  std::lock_guard<std::mutex> lock(g_timed_mutex);
+  *item_ms = 0.f;
+  *reduce_ms = 0.f;
+  *launches = (int)g_timed_used;
+  if (g_timed_used > 0) {
+    g_timed[g_timed_used - 1].item = g_timed_item;
+    g_timed[g_timed_used - 1].reduce = g_timed_reduce;
+  }
+  for (size_t i = 0; i < g_timed_used; ++i) {
+    TimedLaunch& t = g_timed[i];
+    hipError_t e = hipEventSynchronize(t.ev[2]);
+    if (e != hipSuccess) return e;
+    float ms = 0.f;
+    if (t.item && hipEventElapsedTime(&ms, t.ev[0], t.ev[1]) == hipSuccess) *item_ms += ms;
+    if (t.reduce && hipEventElapsedTime(&ms, t.ev[1], t.ev[2]) == hipSuccess) *reduce_ms += ms;
+  }
+  g_timed_used = 0;
   return hipSuccess;
 }
 #endif  // CUMF_SLICE_COMMON
@@ -1194,6 +1248,7 @@ static hipError_t launch_nb(const KernelArgs& a, long n_items, long n_mrows, hip
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
+  timing_begin();
   if (g_timing) (void)hipEventRecord(g_ev[0], stream);
   g_timed_item = n_items > 0;
   g_timed_reduce = n_mrows > 0;
@@ -1528,6 +1583,7 @@ bool wave_batched_path(int f, int mode) {
 hipError_t launch_half_iteration(const KernelArgs& a, int mode, long n_items, long n_mrows, hipStream_t stream,
                                  const PlanLists* lists) {
   if (lists != nullptr && wave_batched_path(a.f, mode)) {
+    timing_begin();
     if (g_timing) (void)hipEventRecord(g_ev[0], stream);
     g_timed_item = true;
     g_timed_reduce = false;
@@ -1545,6 +1601,7 @@ hipError_t launch_half_iteration(const KernelArgs& a, int mode, long n_items, lo
     return e;
   }
   if (wave_path_available(a.f, mode)) {
+    timing_begin();
     if (g_timing) (void)hipEventRecord(g_ev[0], stream);
     g_timed_item = n_items > 0;
     g_timed_reduce = n_mrows > 0;

@@ -16,6 +16,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -272,6 +273,30 @@ struct Scratch {
 std::mutex g_scratch_mutex;
 std::map<std::tuple<int, hipStream_t, int>, Scratch> g_scratch;
 std::map<int, int*> g_fast_flag;  // per device (range report of gram mode "fast")
+// Host threads that are inside a launch sequence using pooled pointers, per device (a second host thread
+// between its Gram launch and its reduce / LU launch must not have its tile buffer freed by another thread's
+// cumf_release_scratch).  An entry point that takes pooled scratch holds a ScratchLease until its last launch is
+// enqueued; cumf_release_scratch waits until no lease of its device is held, then synchronises the device (the
+// enqueued kernels finish) and frees that device's entries only.
+std::map<int, int> g_scratch_users;
+std::condition_variable g_scratch_cv;
+struct ScratchLease {
+  int dev = 0;
+  ScratchLease() {
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    ++g_scratch_users[dev];
+  }
+  ~ScratchLease() {
+    {
+      std::lock_guard<std::mutex> lock(g_scratch_mutex);
+      --g_scratch_users[dev];
+    }
+    g_scratch_cv.notify_all();
+  }
+  ScratchLease(const ScratchLease&) = delete;
+  ScratchLease& operator=(const ScratchLease&) = delete;
+};
 
 int scratch_get(hipStream_t stream, int kind, size_t bytes, void** out) {
   int dev = 0;
@@ -398,7 +423,7 @@ int fast_words(const cumf_plan_t* p, const float* gather, int f, hipStream_t str
   return 0;
 }
 
-int g_last_error = 0;
+thread_local int g_last_error = 0;  // per host thread: concurrent doALS calls do not see each other's state
 
 }  // namespace
 
@@ -422,16 +447,28 @@ extern "C" int cumf_gram_fast_status(int* flags) {
   return 0;
 }
 
-// Frees the pooled scratch of every device (tile buffers, pre-split tables, range flags); doALS calls it on exit.
+// Frees the pooled scratch of the CURRENT device (tile buffers, pre-split tables, range flag; all streams); doALS
+// calls it on exit.  Waits for host threads that are inside a launch sequence on this device (ScratchLease) and for
+// the device itself; other devices' entries are left alone.
 extern "C" int cumf_release_scratch(void) {
-  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  int dev = 0;
+  CUMF_HIP_CHECK(hipGetDevice(&dev));
+  std::unique_lock<std::mutex> lock(g_scratch_mutex);
+  g_scratch_cv.wait(lock, [&] { return g_scratch_users[dev] == 0; });
   CUMF_HIP_CHECK(hipDeviceSynchronize());
-  for (auto& kv : g_scratch)
-    if (kv.second.ptr) (void)hipFree(kv.second.ptr);
-  g_scratch.clear();
-  for (auto& kv : g_fast_flag)
-    if (kv.second) (void)hipFree(kv.second);
-  g_fast_flag.clear();
+  for (auto it = g_scratch.begin(); it != g_scratch.end();) {
+    if (std::get<0>(it->first) == dev) {
+      if (it->second.ptr) (void)hipFree(it->second.ptr);
+      it = g_scratch.erase(it);
+    } else {
+      ++it;
+    }
+  }
+  auto ff = g_fast_flag.find(dev);
+  if (ff != g_fast_flag.end()) {
+    if (ff->second) (void)hipFree(ff->second);
+    g_fast_flag.erase(ff);
+  }
   return 0;
 }
 
@@ -499,6 +536,7 @@ extern "C" int cumf_als_update_fused(const cumf_plan_t* p, const int* colidx, co
                     "in LDS (f <= 128), the fused LU its packed upper triangle (f <= 200)\n", f);
     return (int)hipErrorInvalidValue;
   }
+  ScratchLease lease;  // pooled tile buffer / pre-split table stay ours until the last launch below is enqueued
   KernelArgs a = base_args(p, colidx, val, gather, f, lambda);
   a.update = update;
   a.cg_iters = cg_iters;
@@ -528,6 +566,7 @@ int get_hermitian_any(const char* who, const cumf_plan_t* p, const int* colidx, 
     fprintf(stderr, "%s: plan/f mismatch\n", who);
     return (int)hipErrorInvalidValue;
   }
+  ScratchLease lease;
   KernelArgs a = base_args(p, colidx, val, gather, f, lambda);
   a.tt = static_cast<float*>(tt);
   a.tt_half = storage == 1;
@@ -651,6 +690,12 @@ extern "C" int cumf_set_kernel_timing(int enable) {
 extern "C" int cumf_last_kernel_ms(float* item_kernel_ms, float* reduce_kernel_ms) {
   if (!item_kernel_ms || !reduce_kernel_ms) return (int)hipErrorInvalidValue;
   CUMF_HIP_CHECK(last_kernel_ms(item_kernel_ms, reduce_kernel_ms));
+  return 0;
+}
+
+extern "C" int cumf_kernel_ms_since_reset(float* item_kernel_ms, float* reduce_kernel_ms, int* launches) {
+  if (!item_kernel_ms || !reduce_kernel_ms || !launches) return (int)hipErrorInvalidValue;
+  CUMF_HIP_CHECK(kernel_ms_since_reset(item_kernel_ms, reduce_kernel_ms, launches));
   return 0;
 }
 

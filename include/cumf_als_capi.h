@@ -193,6 +193,10 @@ int cumf_get_gram_mode(void);
  */
 int cumf_set_kernel_timing(int enable);
 int cumf_last_kernel_ms(float* item_kernel_ms, float* reduce_kernel_ms);
+/* The same two durations SUMMED over every half-iteration launch sequence since the previous call (or since timing
+ * was enabled), and their count: a half-iteration made of several launches (X_BATCH / THETA_BATCH plans, the
+ * pipeline pieces of the multi-GPU gather scheme) is read with one call.  Waits for those launches; resets the sum. */
+int cumf_kernel_ms_since_reset(float* item_kernel_ms, float* reduce_kernel_ms, int* launches);
 /* Demangled name of the Gram(+solve) kernel the last half-iteration dispatched, as rocprofv3 prints it
  * (e.g. "cumf::als_wave_kernel<7, 1, 100, 0>"); buf receives a NUL-terminated string ("" before any launch). */
 int cumf_last_kernel_name(char* buf, int cap);
@@ -202,8 +206,10 @@ int cumf_last_kernel_name(char* buf, int cap);
  * convention -- print and exit, als.h:628-665 -- is kept for HIP failures only).  Reading clears it. */
 enum { CUMF_ERR_FAST_RANGE = 10001 };
 int cumf_last_error(void);
-/* Frees the scratch the library keeps between calls (tile buffers of the f >= 160 LU, pre-split tables of gram
- * mode "fast"; one per device and stream, grow-only).  doALS calls it before returning. */
+/* Frees the scratch the library keeps between calls on the CURRENT device (tile buffers of the f >= 160 LU,
+ * pre-split tables of gram mode "fast"; one per device and stream, grow-only).  Safe against other host threads:
+ * it waits for entry points that are mid-sequence on this device and leaves other devices' buffers alone.
+ * doALS calls it before returning. */
 int cumf_release_scratch(void);
 
 /* Row pointers of a matrix with 2^31 or more ratings handed over as 4-byte values (doALS takes `const int*`; the

@@ -182,14 +182,17 @@ def test_pack_unpack_upper(alslib):
         assert torch.equal(back, a)
 
 
+@pytest.mark.parametrize("launch", ["torchrun", "self"])
 @pytest.mark.parametrize("args", [["--scheme", "gather"], ["--shape", "hugewiki", "--scheme", "reduce", "--solver", "cg"],
                                   ["--scheme", "reduce"]])
-def test_bench_world2_branch_runs(alslib, args):
+def test_bench_world2_branch_runs(alslib, args, launch):
     """bench.py's `world > 1` branch (process group, from_device_ratings / from_local_slab,
     barrier, MAX all-reduce of the elapsed time) executed with TWO ranks, launched exactly as the driver launches
     it (python -m torch.distributed.run ... bench.py --gpus 2) -- on the one GPU of this box, so gloo stands in
     for RCCL (CUMF_BENCH_BACKEND=gloo: collectives staged through the host) and both ranks share cuda:0.  The
-    shape is shrunk (--scale): the line is checked for shape, not for speed."""
+    shape is shrunk (--scale): the line is checked for shape, not for speed.
+    launch = "self" (VERDICT r03 next 2a): plain `python bench.py --gpus 2` without a torchrun environment must
+    re-launch itself under torch.distributed.run and print the same single line, with the per-rank diagnostics."""
     torch = pytest.importorskip("torch")
     if not torch.cuda.is_available():
         pytest.fail("-m gpu tests need a GPU")
@@ -202,9 +205,16 @@ def test_bench_world2_branch_runs(alslib, args):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, CUMF_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "1", "--scale", "0.05", "--no-cpu-baseline"] + args
+    if launch == "self":
+        if args != ["--scheme", "gather"]:
+            pytest.skip("self-launch is exercised once")
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+            env.pop(k, None)
+        cmd = [sys.executable, os.path.join(root, "bench.py")]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py")]
+    cmd += ["--gpus", "2", "--steps", "2", "--warmup", "1", "--scale", "0.05", "--no-cpu-baseline"] + args
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -213,3 +223,12 @@ def test_bench_world2_branch_runs(alslib, args):
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1
     assert line["value"] > 0 and np.isfinite(line["value"]) and line["ms_per_step"] > 0
     assert line["scaling"] == ("weak" if "hugewiki" in args else "strong")
+    # per-rank diagnostics of the N > 1 line: two ranks seen, kernel time inside the half-iteration time
+    rk = line["ranks"]
+    assert rk["n_ranks_seen"] == 2 and rk["self_launched"] == (launch == "self")
+    assert rk["scheme"] == ("reduce" if "reduce" in args else "gather")
+    pr = rk["per_rank"]
+    for side in ("x", "theta"):
+        assert len(pr[f"{side}_half_ms"]) == 2 and len(pr[f"{side}_kernel_ms"]) == 2
+        for h, k, n_l in zip(pr[f"{side}_half_ms"], pr[f"{side}_kernel_ms"], pr[f"{side}_launches"]):
+            assert 0 < k <= h * 1.05 and n_l >= 1, (side, h, k, n_l)

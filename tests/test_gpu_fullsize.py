@@ -95,9 +95,10 @@ def _rel_residuals(sub, gather, xs, f, lam):
 def _check_rows_against_oracle(oracle, indptr, indices, data, gather, warm, got, rows, f, lam, solver, what, cg_iters=6,
                                strict=False):
     """HIP rows vs the oracle's on the same inputs.
-    LU: max |x_hip - x_64| <= max(2e-5, 2 x the fp32 oracle's own distance from the fp64 oracle) of the scale --
-        on rows of 10^4 .. 10^5 ratings the reference's sequential fp32 chain is itself 1e-4 off, so the fp64
-        evaluation of the same algorithm is the yardstick and the fp32 oracle sets the allowance.
+    LU: per row, max |x_hip - x_64| relative to the row's own max |x_64|; median, 99th percentile and maximum over the
+        sampled rows <= the same statistic of the fp32 oracle + 1e-5 -- on rows of 10^4 .. 10^5 ratings the
+        reference's sequential fp32 chain is itself 1e-4 off, so the fp64 evaluation of the same algorithm is the
+        yardstick and the fp32 oracle sets the allowance (1 x, not 2 x: the HIP rows are closer to fp64 than it).
     CG, strict (cg_iters <= 3, where the recurrence is still well conditioned in fp32): EVERY row within
         2e-4 * max(1, |x|) of the fp32 oracle, element-wise.
     CG(6) = the reference's CG_ITER: on systems the first iterations have already solved to fp32 level the
@@ -112,12 +113,15 @@ def _check_rows_against_oracle(oracle, indptr, indices, data, gather, warm, got,
     assert np.array_equal(np.isnan(xh), np.isnan(x32)), what
     if solver == "lu":
         x64, _ = _oracle_rows(oracle, indptr, indices, data, gather, warm, rows, f, lam, solver, dtype=np.float64)
-        scale = np.abs(x64).max()
-        e_hip = np.abs(xh - x64).max() / scale
-        e_o32 = np.abs(x32 - x64).max() / scale
-        print(f"{what}: rows {len(rows)}  hip-vs-fp64 {e_hip:.3e}  oracle32-vs-fp64 {e_o32:.3e}  "
-              f"hip-vs-oracle32 {np.abs(xh - x32).max() / scale:.3e}")
-        assert e_hip <= max(2e-5, 2.0 * e_o32), (what, e_hip, e_o32)
+        # per row, relative to the row's own scale (not a global scale, not 2 x)
+        den = np.maximum(np.abs(x64).max(1), 1e-30)
+        e_hip = np.abs(xh - x64).max(1) / den
+        e_o32 = np.abs(x32 - x64).max(1) / den
+        stats = lambda v: (float(np.median(v)), float(np.quantile(v, 0.99)), float(v.max()))
+        print(f"{what}: rows {len(rows)}  per-row relative |x - x64| (median, q99, max): hip {stats(e_hip)}  "
+              f"oracle32 {stats(e_o32)}  hip-vs-oracle32 {stats(np.abs(xh - x32).max(1) / den)}")
+        for sh, so in zip(stats(e_hip), stats(e_o32)):
+            assert sh <= so + 1e-5, (what, stats(e_hip), stats(e_o32))
         return
     if strict:
         el = np.abs(xh - x32).max(1) / np.maximum(1.0, np.abs(x32).max(1))
@@ -406,3 +410,108 @@ def test_more_than_2_31_ratings_on_one_gpu(oracle):
     res = _residuals(torch.from_numpy(rowptr), colidx, val, theta, x, mid, lam)
     assert res <= 5e-2, res
     assert bool((x.abs().sum(dim=1) > 0).all())
+
+
+def _doals_cxx_symbol(alslib, d, thetaT, XT, m, n, f, nnz, nnz_test, lam, iters, x_batch, theta_batch, solver):
+    """The reference's own entry point under its Itanium name (als.h:676-681), called as main.cpp:141-146 calls it:
+    22 host pointers / scalars, factors in and out, the solver chosen the way the reference chooses it (a build
+    switch there, als.cu:28; the environment here).  The per-iteration RMSE is scraped from the stdout lines
+    (als.cu:991,1019), as the reference's print-test-result.sh:8-11 does.  Returns (final test RMSE, log[iters, 2])."""
+    import ctypes as C
+    import os
+    import re
+    import tempfile
+
+    fn = getattr(alslib, "_Z5doALSPKiS0_PKfS0_S0_S2_S0_PfS3_S0_S0_S2_iiillfiiii")
+    fn.restype = C.c_float
+    fn.argtypes = [C.c_void_p] * 12 + [C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_float, C.c_int, C.c_int, C.c_int,
+                                       C.c_int]
+    hp = lambda a: C.c_void_p(a.ctypes.data)
+    keep = {k: os.environ.get(k) for k in ("CUMF_ALS_SOLVER", "CUMF_ALS_QUIET")}
+    os.environ["CUMF_ALS_SOLVER"] = solver
+    os.environ.pop("CUMF_ALS_QUIET", None)
+    libc = C.CDLL(None)
+    libc.fflush(None)
+    saved = os.dup(1)
+    with tempfile.TemporaryFile(mode="w+b") as tmp:
+        os.dup2(tmp.fileno(), 1)
+        try:
+            rm = fn(hp(d["csr_indptr"]), hp(d["csr_indices"]), hp(d["csr_data"]), hp(d["csc_indices"]), hp(d["csc_indptr"]),
+                    hp(d["csc_data"]), hp(d["coo_row"]), hp(thetaT), hp(XT), hp(d["test_row"]), hp(d["test_col"]),
+                    hp(d["test_data"]), m, n, f, nnz, nnz_test, lam, iters, x_batch, theta_batch, 0)
+            libc.fflush(None)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+            for k, v in keep.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        tmp.seek(0)
+        text = tmp.read().decode()
+    tr = [float(v) for v in re.findall(r"Train RMSE in iter \d+: ([-0-9.naninf]+)", text)]
+    te = [float(v) for v in re.findall(r"Test RMSE in iter \d+: ([-0-9.naninf]+)", text)]
+    assert len(tr) == iters and len(te) == iters, text[-400:]
+    return float(rm), np.stack([tr, te], axis=1), text
+
+
+@pytest.mark.parametrize("solver", ["lu", "cg"])
+def test_headline_doals_rmse_log_matches_oracle(oracle, alslib, solver):
+    """VERDICT r03 item 1 / north_star "RMSE to 1e-4 on the same inputs": the reference's loop (als.cu:727-1022: update
+    X, update Theta, train RMSE :979-991, test RMSE :1006-1019) for THREE full iterations at the headline shape
+    (17 770 x 480 189, 99 072 112 ratings, f = 100, lambda = 0.048) with the reference's own batch setting
+    X_BATCH = 1, THETA_BATCH = 3 (test_als.sh:16) through the C++ symbol doALS, against oracle_doALS on the same
+    matrix, the same srand(0) initial factors (main.cpp:72-78), the same truncated test grid (als.cu:1006).
+    Train and test RMSE of every iteration within 1e-4; LU: the factors of the last iteration too."""
+    _need_gpu()
+    from cumf_als_amd import datagen
+
+    shp = datagen.SHAPES["netflix"]
+    m, n, nnz, nnz_test, lam, iters = shp["m"], shp["n"], shp["nnz"], shp["nnz_test"], shp["lam"], 3
+    r = datagen.synth_ratings(m, n, nnz, nnz_test, seed=0, device="cuda")
+    d = r.numpy()
+    del r
+    torch.cuda.empty_cache()
+    th0, x0 = oracle.init_factors(m, n, F)
+    th_h, x_h = th0.copy(), x0.copy()
+    rm_h, log_h, text = _doals_cxx_symbol(alslib, d, th_h, x_h, m, n, F, nnz, nnz_test, lam, iters, 1, 3, solver)
+    assert ("CG solver with fp32." in text) == (solver == "cg")
+    th_o, x_o = th0.copy(), x0.copy()
+    rm_o, log_o = oracle.do_als(d, th_o, x_o, m, n, F, lam, iters, x_batch=1, theta_batch=3, solver=solver)
+    dlog = np.abs(log_h - log_o)
+    print(f"headline doALS {solver}: hip log {log_h.tolist()}  oracle log {log_o.tolist()}  max |d| {dlog.max():.3e}  "
+          f"final {rm_h:.7f} vs {rm_o:.7f}")
+    assert dlog.max() <= 1e-4, (log_h, log_o)
+    assert abs(rm_h - rm_o) <= 1e-4
+    assert np.array_equal(np.isnan(th_h), np.isnan(th_o)) and np.array_equal(np.isnan(x_h), np.isnan(x_o))
+    ft, fx = np.isfinite(th_o), np.isfinite(x_o)
+
+    def dist(a, b, fin):
+        """(max-abs relative to the factor scale, per-row relative 2-norm distances)"""
+        rows = np.linalg.norm(np.where(fin, a - b, 0.0), axis=1) / np.maximum(np.linalg.norm(np.where(fin, b, 0.0), axis=1), 1e-30)
+        return float(np.abs(a[fin] - b[fin]).max() / np.abs(b[fin]).max()), rows
+
+    stats = lambda v: (float(np.median(v)), float(np.quantile(v, 0.99)), float(v.max()))
+    e_t, row_t = dist(th_h, th_o, ft)
+    e_x, row_x = dist(x_h, x_o, fx)
+    print(f"headline doALS {solver}: factors after {iters} iterations vs the fp32 oracle, max-abs relative: Theta {e_t:.3e}  "
+          f"X {e_x:.3e}; per-row relative (median, q99, max): Theta {stats(row_t)}  X {stats(row_x)}")
+    if solver == "lu":
+        # Three iterations of an unpivoted fp32 LU on rows of up to 2 x 10^5 ratings: the fp32 oracle's own sequential
+        # chain is 1e-4 off the fp64 evaluation per half-iteration (bench.py parity_at_scale) and that compounds, so
+        # the yardstick is the SAME loop evaluated in fp64 by the oracle: the HIP factors must be within 1e-4 of it on
+        # the typical row and no farther from it than the fp32 oracle is (median, 99th percentile, maximum + 1e-5),
+        # and within 1e-3 of the fp32 oracle everywhere.
+        th_64, x_64 = th0.copy(), x0.copy()
+        _, log_64 = oracle.do_als(d, th_64, x_64, m, n, F, lam, iters, x_batch=1, theta_batch=3, solver=solver,
+                                  dtype=np.float64)
+        h_t, h_x = dist(th_h, th_64, ft)[1], dist(x_h, x_64, fx)[1]
+        o_t, o_x = dist(th_o, th_64, ft)[1], dist(x_o, x_64, fx)[1]
+        print(f"headline doALS lu: per-row relative distance from the fp64 oracle (median, q99, max): Theta hip {stats(h_t)} "
+              f"oracle32 {stats(o_t)}  X hip {stats(h_x)} oracle32 {stats(o_x)};  RMSE log vs fp64: hip "
+              f"{np.abs(log_h - log_64).max():.3e} oracle32 {np.abs(log_o - log_64).max():.3e}")
+        assert np.median(h_t) <= 1e-4 and np.median(h_x) <= 1e-4, (stats(h_t), stats(h_x))
+        for sh, so in zip(stats(h_t) + stats(h_x), stats(o_t) + stats(o_x)):
+            assert sh <= so + 1e-5, (stats(h_t), stats(o_t), stats(h_x), stats(o_x))
+        assert e_t <= 1e-3 and e_x <= 1e-3, (e_t, e_x)
