@@ -177,6 +177,30 @@ def update_fused(plan: Plan, colidx, val, gather, update, lambda_: float, solver
     return update
 
 
+SSE_BINS = 1024  # CUMF_SSE_BINS
+
+
+def fused_sse_available(plan: Plan, solver="cg") -> bool:
+    return bool(_libmod.load().cumf_fused_sse_available(plan._h, _solver_id(solver)))
+
+
+def update_fused_sse(plan: Plan, colidx, val, gather, update, lambda_: float, solver="cg", cg_iters: int = 6, bins=None):
+    """`update_fused` + the train SSE of the plan's rows for free (cumf_als_update_fused_sse): returns the fp64 bins
+    tensor [SSE_BINS] it ADDED to (zeroed here when not passed in); the SSE is `bins.sum()`."""
+    import torch
+
+    lib = _libmod.load()
+    if bins is None:
+        bins = torch.zeros(SSE_BINS, dtype=torch.float64, device=update.device)
+    _libmod.check(lib.cumf_check_gather_table(gather.shape[0], plan.f, _solver_id(solver), 0), "cumf_check_gather_table")
+    _libmod.check(lib.cumf_plan_set_gather_rows(plan._h, int(gather.shape[0])), "cumf_plan_set_gather_rows")
+    _libmod.check(lib.cumf_als_update_fused_sse(plan._h, _dp(colidx, torch.int32), _dp(val, torch.float32),
+                                                _dp(gather, torch.float32), _dp(update, torch.float32), plan.f,
+                                                float(lambda_), _solver_id(solver), int(cg_iters),
+                                                _dp(bins, torch.float64), _stream()), "cumf_als_update_fused_sse")
+    return bins
+
+
 def get_hermitian(plan: Plan, colidx, val, gather, lambda_: float, tt=None, rhs=None, want_rhs=True, half=False):
     """Materialise the Gram batch tt[rows,f,f] (+ rhs[rows,f]) of the plan's rows (cumf_get_hermitian).
     half=True (or a float16 `tt`): fp16 storage of the Gram, cumf_get_hermitian_fp16 (als.cu:335-441)."""
@@ -443,6 +467,20 @@ class ALSEngine:
     def update_theta(self):
         """update Theta from XT over the CSC columns (als.cu:857-964)."""
         self._half(self.t_plans, self.r.csc_indices, self.r.csc_data, self.XT, self.thetaT)
+
+    def update_theta_with_train_sse(self):
+        """update Theta AND return the train SSE of the new factors (fp64 scalar tensor) from the same kernels
+        (cumf_als_update_fused_sse); None -- after a plain update -- when the plans cannot deliver it."""
+        import torch
+
+        if not (self.fused and all(fused_sse_available(p, self.solver) for p in self.t_plans)):
+            self.update_theta()
+            return None
+        bins = torch.zeros(SSE_BINS, dtype=torch.float64, device=self.device)
+        for p in self.t_plans:
+            update_fused_sse(p, self.r.csc_indices, self.r.csc_data, self.XT, self.thetaT, self.lam, self.solver,
+                             self.cg_iters, bins)
+        return bins.sum()
 
     def rmse(self, exact_test_grid: bool = True, surpass_nan: bool = False):
         """(train, test) RMSE as als.cu:966-1020."""

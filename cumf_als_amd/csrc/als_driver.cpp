@@ -142,6 +142,7 @@ extern "C" float cumf_doALS_ex(const int* csrRowIndexHostPtr, const int* csrColI
   float* thetaT = to_device(thetaTHost, (size_t)n * f);
   float* XT = to_device(XTHost, (size_t)m * f);
   double* d_sse = to_device<double>(nullptr, 2);
+  double* d_bins = to_device<double>(nullptr, CUMF_SSE_BINS);  // fused train SSE of the Theta update
 
   // 2^31 or more ratings: the 4-byte row pointers have wrapped (hugewiki.cu:1973 reads them as unsigned)
   std::vector<long long> csr64, csc64;
@@ -166,12 +167,27 @@ extern "C" float cumf_doALS_ex(const int* csrRowIndexHostPtr, const int* csrColI
     rhs = to_device<float>(nullptr, (size_t)maxb * f);
   }
 
-  auto half_iteration = [&](Side& s, const float* gather, float* update) {
+  // Train RMSE (als.cu:979-991) without its own pass: the Theta update delivers sum (r - x_u . theta_v)^2 of its
+  // columns from the systems it has just solved (cumf_als_update_fused_sse).  Off -- the RMSE kernel runs as in the
+  // reference -- with CUMF_ALS_RMSE=kernel, with SURPASS_NAN semantics (als.cu:201-211 skip NaN factor entries inside
+  // a dot product: not expressible on the system level), and when a Theta plan has rows the wave kernel does not solve.
+  bool fuse_rmse = fused && !surpass_nan;
+  {
+    const char* e = getenv("CUMF_ALS_RMSE");
+    if (e && strcmp(e, "kernel") == 0) fuse_rmse = false;
+    for (cumf_plan_t* p : st.plans) fuse_rmse = fuse_rmse && cumf_fused_sse_available(p, solver);
+  }
+
+  auto half_iteration = [&](Side& s, const float* gather, float* update, double* sse_bins) {
     for (int b = 0; b < s.nbatch; ++b) {
       if (fused) {
         if (solver == CUMF_SOLVER_CG && !quiet) printf("\tCG solver with fp32.\n");
-        DRV_CHECK(cumf_als_update_fused(s.plans[b], s.d_colidx, s.d_val, gather, update, f, lambda, solver,
-                                        cg_iters, nullptr));
+        if (sse_bins)
+          DRV_CHECK(cumf_als_update_fused_sse(s.plans[b], s.d_colidx, s.d_val, gather, update, f, lambda, solver,
+                                              cg_iters, sse_bins, nullptr));
+        else
+          DRV_CHECK(cumf_als_update_fused(s.plans[b], s.d_colidx, s.d_val, gather, update, f, lambda, solver,
+                                          cg_iters, nullptr));
       } else {
         float* xb = update + (size_t)s.offset[b] * f;
         if (tt_fp16) {
@@ -195,8 +211,9 @@ extern "C" float cumf_doALS_ex(const int* csrRowIndexHostPtr, const int* csrColI
   bool range_error = false;
   if (!quiet) printf("*******start iterations...\n");
   for (int iter = 0; iter < ITERS; iter++) {
-    half_iteration(sx, thetaT, XT);  // update X      (als.cu:727-855)
-    half_iteration(st, XT, thetaT);  // update Theta  (als.cu:857-964)
+    half_iteration(sx, thetaT, XT, nullptr);  // update X      (als.cu:727-855)
+    if (fuse_rmse) DRV_CHECK(hipMemsetAsync(d_bins, 0, CUMF_SSE_BINS * sizeof(double), nullptr));
+    half_iteration(st, XT, thetaT, fuse_rmse ? d_bins : nullptr);  // update Theta  (als.cu:857-964)
     if (cumf_get_gram_mode() == CUMF_GRAM_FAST) {
       int flags = 0;
       DRV_CHECK(cumf_gram_fast_status(&flags));
@@ -215,11 +232,19 @@ extern "C" float cumf_doALS_ex(const int* csrRowIndexHostPtr, const int* csrColI
     // -- one short of covering the set (als.cu:1006) -- yet divides by nnz_test.
     long count_test = exact_test_grid ? nnz_test : ((nnz_test - 1) / 256) * 256;
     if (count_test < 0) count_test = 0;
-    DRV_CHECK(cumf_sse(csrVal, cooRowIndex, csrColIndex, thetaT, XT, nnz, f, surpass_nan, d_sse, nullptr));
+    if (!fuse_rmse)
+      DRV_CHECK(cumf_sse(csrVal, cooRowIndex, csrColIndex, thetaT, XT, nnz, f, surpass_nan, d_sse, nullptr));
     DRV_CHECK(cumf_sse(cooVal_test, cooRowIndex_test, cooColIndex_test, thetaT, XT, count_test, f, surpass_nan,
                        d_sse + 1, nullptr));
     double sse[2];
     DRV_CHECK(hipMemcpy(sse, d_sse, sizeof(sse), hipMemcpyDeviceToHost));
+    if (fuse_rmse) {
+      double bins[CUMF_SSE_BINS];
+      DRV_CHECK(hipMemcpy(bins, d_bins, sizeof(bins), hipMemcpyDeviceToHost));
+      sse[0] = 0.0;
+      for (int i = 0; i < CUMF_SSE_BINS; ++i) sse[0] += bins[i];  // fixed order (als.cu:988: cublasSasum over the bins)
+      if (sse[0] < 0.0) sse[0] = 0.0;  // a perfect fit can come out as -1e-9 of sum r^2
+    }
     const float rmse_train = (float)sqrt(sse[0] / (double)nnz);
     final_rmse = (float)sqrt(sse[1] / (double)nnz_test);
     if (!quiet) {
@@ -241,7 +266,7 @@ extern "C" float cumf_doALS_ex(const int* csrRowIndexHostPtr, const int* csrColI
   for (cumf_plan_t* p : sx.plans) cumf_plan_destroy(p);
   for (cumf_plan_t* p : st.plans) cumf_plan_destroy(p);
   void* bufs[] = {csrColIndex, csrVal, cscRowIndex, cscVal, cooRowIndex, cooRowIndex_test, cooColIndex_test,
-                  cooVal_test, thetaT,  XT,      d_sse,  tt,          rhs};
+                  cooVal_test, thetaT,  XT,      d_sse,  tt,          rhs, d_bins};
   for (void* q : bufs)
     if (q) DRV_CHECK(hipFree(q));
   DRV_CHECK(cumf_release_scratch());  // pooled tile buffers / pre-split tables of the plans above

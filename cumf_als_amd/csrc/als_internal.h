@@ -88,7 +88,11 @@ struct KernelArgs {
   // (presplit_f16x2_kernel) and range violations are OR-ed into *fast_flag (bit 0: table, bit 1: ratings)
   int fast_words;
   int* fast_flag;
+  // fused train SSE (als.cu:979-991 folded into the Theta update): when not null, every whole-row item of a wave-kernel
+  // launch adds sum_u (r_uv - x_u . theta_v)^2 of its row to sse_bins[item % kSseBins] (fp64 atomics)
+  double* sse_bins;
 };
+constexpr int kSseBins = 1024;
 
 // Work lists of a plan as the launchers see them (device arrays of als_plan.cpp).
 struct PlanLists {

@@ -164,6 +164,10 @@ struct Stager {
   template <bool FULL>
   __device__ __forceinline__ void gather_val(const float* __restrict__ val, long long begin, int nvalid, int tid) {
     const int r = tid & (kStage - 1);
+    if (val == nullptr) {  // no ratings given (alsUpdateFeature100Host: the right-hand side comes precomputed): zeros
+      rvv = 0.f;
+      return;
+    }
     const float* vbase = val + begin;  // wave-uniform
     rvv = vbase[(unsigned)(FULL ? r : (r < nvalid ? r : nvalid - 1))];
   }

@@ -524,8 +524,9 @@ extern "C" int cumf_fused_available(int f, int solver) {
   return fused_supported(f, mode) || wave_path_available(f, mode) || wave_batched_path(f, mode);
 }
 
-extern "C" int cumf_als_update_fused(const cumf_plan_t* p, const int* colidx, const float* val, const float* gather,
-                                     float* update, int f, float lambda, int solver, int cg_iters, void* stream) {
+namespace {
+int update_fused_impl(const cumf_plan_t* p, const int* colidx, const float* val, const float* gather, float* update, int f,
+                      float lambda, int solver, int cg_iters, double* sse_bins, void* stream) {
   if (!p || f != p->f) {
     fprintf(stderr, "cumf_als_update_fused: plan/f mismatch\n");
     return (int)hipErrorInvalidValue;
@@ -540,6 +541,7 @@ extern "C" int cumf_als_update_fused(const cumf_plan_t* p, const int* colidx, co
   KernelArgs a = base_args(p, colidx, val, gather, f, lambda);
   a.update = update;
   a.cg_iters = cg_iters;
+  a.sse_bins = sse_bins;
   const int mode = (solver == CUMF_SOLVER_LU) ? kModeLU : kModeCG;
   PlanLists lists{};
   const bool batched = wave_batched_path(f, mode);
@@ -556,6 +558,33 @@ extern "C" int cumf_als_update_fused(const cumf_plan_t* p, const int* colidx, co
   CUMF_HIP_CHECK(launch_half_iteration(a, mode, p->n_items, p->n_mrows, static_cast<hipStream_t>(stream),
                                        batched ? &lists : nullptr));
   return 0;
+}
+}  // namespace
+
+extern "C" int cumf_als_update_fused(const cumf_plan_t* p, const int* colidx, const float* val, const float* gather,
+                                     float* update, int f, float lambda, int solver, int cg_iters, void* stream) {
+  return update_fused_impl(p, colidx, val, gather, update, f, lambda, solver, cg_iters, nullptr, stream);
+}
+
+// Can the half-iteration of this plan also deliver the train SSE of its rows (cumf_als_update_fused_sse)?  Yes when
+// every row is solved inside the wave-per-item kernel: 16 <= f <= 111, gram mode not "exact", no chunked row in the plan.
+extern "C" int cumf_fused_sse_available(const cumf_plan_t* p, int solver) {
+  if (!p) return 0;
+  const int mode = solver == CUMF_SOLVER_LU ? kModeLU : kModeCG;
+  return wave_path_available(p->f, mode) && p->n_mrows == 0;
+}
+
+// cumf_als_update_fused + the train SSE of the updated rows for free (als.cu:979-991 folded into the update, see
+// wave_tile_ff in als_wave.hip): sum over the plan's rows of sum_u (r - x_u . t)^2 is ADDED, spread over the
+// CUMF_SSE_BINS fp64 words of sse_bins (device memory, zeroed by the caller; the total is their sum).
+extern "C" int cumf_als_update_fused_sse(const cumf_plan_t* p, const int* colidx, const float* val, const float* gather,
+                                         float* update, int f, float lambda, int solver, int cg_iters, double* sse_bins,
+                                         void* stream) {
+  if (!sse_bins || !cumf_fused_sse_available(p, solver)) {
+    fprintf(stderr, "cumf_als_update_fused_sse: not available for this plan (cumf_fused_sse_available)\n");
+    return (int)hipErrorInvalidValue;
+  }
+  return update_fused_impl(p, colidx, val, gather, update, f, lambda, solver, cg_iters, sse_bins, stream);
 }
 
 namespace {
@@ -751,12 +780,22 @@ void alsUpdateFeature100Host(const int batch_offset, const int* csrRowIndex, con
   std::vector<int> rowptr((size_t)m + 1);
   hipError_t e = hipMemcpy(rowptr.data(), csrRowIndex, rowptr.size() * sizeof(int), hipMemcpyDeviceToHost);
   if (e != hipSuccess) fail("row pointer", (int)e);
-  const long long nnz = rowptr[(size_t)m];
+  // 2^31 or more ratings: the 4-byte row pointer has wrapped (hugewiki.cu:1973 reads it as unsigned): widen it; a row
+  // pointer that is not non-decreasing as unsigned values is rejected by the plan (negative row lengths)
+  std::vector<long long> rowptr64((size_t)m + 1);
+  {
+    long long hi = 0;
+    unsigned prev = (unsigned)rowptr[0];
+    rowptr64[0] = prev;
+    for (long i = 1; i <= m; ++i) {
+      const unsigned cur = (unsigned)rowptr[(size_t)i];
+      if (cur < prev) hi += 1ll << 32;
+      rowptr64[(size_t)i] = hi + cur;
+      prev = cur;
+    }
+  }
   // the rating slot of the gathered rows (the fused right-hand side) reads zeros: this entry point has no ratings
-  float* zeros = nullptr;
-  if ((e = hipMalloc(reinterpret_cast<void**>(&zeros), (size_t)std::max<long long>(nnz, 1) * sizeof(float))) != hipSuccess)
-    fail("rating stand-in", (int)e);
-  if ((e = hipMemset(zeros, 0, (size_t)std::max<long long>(nnz, 1) * sizeof(float))) != hipSuccess) fail("memset", (int)e);
+  // (val == nullptr: the kernels read their zero row instead)
   const size_t sys_bytes = (size_t)F * F * sizeof(float);
   const long per_batch = std::max<long>(1, (long)(((size_t)4 << 30) / sys_bytes));
   float* tt = nullptr;
@@ -765,9 +804,9 @@ void alsUpdateFeature100Host(const int batch_offset, const int* csrRowIndex, con
   for (long b0 = 0; b0 < rows; b0 += per_batch) {
     const long nb = std::min(per_batch, rows - b0);
     cumf_plan_t* plan = nullptr;
-    int rc = cumf_plan_create(&plan, rowptr.data(), 0, m, batch_offset + b0, batch_offset + b0 + nb, F, 0);
+    int rc = cumf_plan_create(&plan, rowptr64.data(), 1, m, batch_offset + b0, batch_offset + b0 + nb, F, 0);
     if (rc) fail("plan", rc);
-    rc = cumf_get_hermitian(plan, csrColIndex, zeros, thetaT, tt, nullptr, F, lambda, nullptr);
+    rc = cumf_get_hermitian(plan, csrColIndex, nullptr, thetaT, tt, nullptr, F, lambda, nullptr);
     if (rc) fail("Gram", rc);
     rc = cumf_cg_solve_batched(tt, XT + (size_t)b0 * F, ythetaT + (size_t)b0 * F, nb, F, cgIter, nullptr);
     if (rc) fail("CG", rc);
@@ -775,5 +814,4 @@ void alsUpdateFeature100Host(const int batch_offset, const int* csrRowIndex, con
     cumf_plan_destroy(plan);
   }
   (void)hipFree(tt);
-  (void)hipFree(zeros);
 }

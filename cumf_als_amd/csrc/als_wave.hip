@@ -140,8 +140,7 @@ struct Planes<NB, kArithFast> {
 
 // Loop-invariant per-lane state of the gather.  FULL forms assume every rating of the stage
 // exists (16-byte index / rating loads, no selects); the generic forms clamp the index loads to
-// the item and point the ratings past its end at the zero row (their rating value may then be
-// anything finite: it only ever meets zeros).
+// the item, point the ratings past its end at the zero row and zero their rating value.
 template <int NB>
 struct WaveGather {
   const char* lane_base;   // gather table + 4 c
@@ -181,7 +180,7 @@ struct WaveGather {
     // the solver without a merge with a "no stage" path: that merge cost 41 spilled registers in the LU kernel).
     // Its index / rating loads must not touch colidx / val (begin may be the end of the arrays): they read the
     // zero row; "+ 8 g + 1" because the clamped index forms address the item's last rating at base[-1 - 8 g].
-    has_val = is_val && len_ > 0;
+    has_val = is_val && len_ > 0 && a.val != nullptr;  // val == nullptr: no ratings given, the slot reads zeros
     val_base = has_val ? a.val + begin + 8 * g : g_wave_zeros;
     idx_base = len_ > 0 ? a.colidx + begin + 8 * g : reinterpret_cast<const int*>(g_wave_zeros) + 8 * g + 1;
   }
@@ -218,9 +217,15 @@ struct WaveGather {
         st.rv[4 + e] = hi[e];
       }
     } else {
+      // ratings past the end of the item read the item's last rating (in bounds) and are then zeroed: their factor
+      // rows are the zero row, so the right-hand side never saw them, but entry (f, f) of the augmented Gram --
+      // sum r^2, what the fused train SSE starts from (wave_tile_ff) -- would
       const int last = has_val ? len - 1 - (kWaveStage * s + 8 * g) : 7;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) st.rv[e] = vp[e < last ? e : last];
+      for (int e = 0; e < 8; ++e) {
+        const float v = vp[e < last ? e : last];
+        st.rv[e] = e <= last ? v : 0.f;
+      }
     }
   }
 
@@ -491,7 +496,7 @@ template <int NB>
 __host__ __device__ constexpr int wave_stage_lds_floats() { return 64 * 8 * NB; }  // 8 NB chunks of 64 floats
 
 template <int NB, int NQ>
-__device__ __forceinline__ void back_substitute_tiles(const f32x4 (&acc)[NB * (NB + 1) / 2], float* T,
+__device__ __forceinline__ float back_substitute_tiles(const f32x4 (&acc)[NB * (NB + 1) / 2], float* T,
                                                       const float* rdiag, const float* zpad, int f,
                                                       float* __restrict__ x_global, int lane) {
   const int c = lane & 15, g = lane >> 4;
@@ -568,150 +573,348 @@ __device__ __forceinline__ void back_substitute_tiles(const f32x4 (&acc)[NB * (N
       }
     }
   });
+  float ssq = 0.f;  // this lane's share of ||x||^2 (rows past f hold zeros); the fused train SSE wants it
   static_for<NQ>([&](auto qc) {
     constexpr int q = decltype(qc)::value;
     if (lane + 64 * q < f) x_global[lane + 64 * q] = z[q];
+    ssq = fmaf(z[q], z[q], ssq);
   });
+  return ssq;
 }
 
 // ----------------------------------------------------------------------------------
-// Unpivoted Gaussian elimination of [A | b] on the accumulators of ONE wave + back
-// substitution: the content of cublasSgetrfBatched(PivotArray = NULL) + cublasSgetrsBatched
-// (als.cu:77,98 / 146,166).  Panel of four pivots p0 .. p0 + 3 (block row Ip, lane group q):
-//   1. the 4 x 4 pivot block is read out of the diagonal tile with v_readlane and eliminated on
-//      wave-uniform values (four dependent v_rcp_f32): multipliers, composite multipliers
-//      (rows of the inverse of the panel's unit lower triangle) and -1 / u_kk;
-//   2. per live feature block b the four raw panel rows (registers 0..3 of lane group q of tile
-//      (Ip, b)) are broadcast to all lane groups with ds_bpermute_b32; lane group kk forms the
-//      eliminated row p0 + kk at its columns, ub[b], with three FMAs;
-//   3. rank-4 update of every live tile (I, J), I >= Ip: A operand = -ub[I] / u_kk masked to the
-//      rows below the pivot (symmetry: a_i,pk = u'_k,i), B operand = ub[J];
-//   4. the eliminated rows go to the packed row store (zeros at and left of the diagonal inside
-//      the diagonal block, as back_substitute_zeroed expects), the reciprocals to rdiag.
-// Operation order differs from the oracle's right-looking loop; parity is by tolerance.
+// Train SSE of one row for free (round 4; als.cu:191-219 + 979-991 folded into the Theta update).  The rating rides in
+// slot f of the gathered rows, so the Gram pass has also accumulated entry (f, f) of the augmented matrix
+// [Theta r]^T [Theta r]: S = sum r^2.  With G = sum x x^T, b = sum r x, A = G + reg I (reg = lambda n):
+//   sum_u (r - x_u . t)^2 = S - 2 t.b + t^T G t                                   for ANY t;
+//   LU:  the elimination treats row / column f like every other trailing row, so entry (f, f) ends as the Schur
+//        complement S + reg - b^T A^-1 b (the diagonal got reg everywhere, slot f included); with A t = b this is
+//        S + reg - t.b, and t^T G t = t.b - reg |t|^2, hence SSE = (f, f) - reg (1 + |t|^2);
+//   CG:  the tiles are untouched; with the recursive residual r = b - A t:  t^T G t = t.b - t.r - reg |t|^2, hence
+//        SSE = S - t.b - t.r - reg |t|^2  (three dot products on vectors the solver holds anyway).
+// No rating and no factor row is read again.  One fp64 atomic per row into kSseBins bins (the reference's own
+// error bins, als.cu:216, hold fp32 partial sums); rows without ratings contribute nothing.
 // ----------------------------------------------------------------------------------
-template <int NB, int FC>
-__device__ __forceinline__ void lu_wave(f32x4 (&acc)[NB * (NB + 1) / 2], float* T, int f_rt, float reg,
-                                        float* __restrict__ x_global, int lane) {
-  const int f = FC ? FC : f_rt;  // FC != 0: compile-time f, the whole elimination is one basic block
-  const int c = lane & 15, kk = (lane >> 4) & 3;
-  const bool k1 = kk == 1, k2 = kk == 2, k3 = kk == 3;
-  auto sel = [](bool p, float a, float b) { return p ? a : b; };  // flat selects: v_cndmask, no branches
-  const float e1c = k1 ? 1.0f : 0.f, e2c = k2 ? 1.0f : 0.f, e3c = k3 ? 1.0f : 0.f;  // unit diagonal of E
-  static_for<NB>([&](auto ic) {
-    constexpr int t = tile_of<NB>(decltype(ic)::value, decltype(ic)::value);
+template <int NB>
+__device__ __forceinline__ float wave_tile_ff(const f32x4& last_diag, int f) {
+  const int cf = f - 16 * (NB - 1);  // slot f inside the last block: lane (cf >> 2, cf), register cf & 3
+  float v = last_diag[0];
+  v = (cf & 3) == 1 ? last_diag[1] : v;
+  v = (cf & 3) == 2 ? last_diag[2] : v;
+  v = (cf & 3) == 3 ? last_diag[3] : v;
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16 * (cf >> 2) + cf));
+}
+__device__ __forceinline__ void wave_sse_add(double* bins, double sse, int rowlen, int lane) {
+  if (lane == 0 && rowlen > 0) atomicAdd(bins + (blockIdx.x & (kSseBins - 1)), sse);
+}
+
+// ----------------------------------------------------------------------------------
+// Unpivoted Gaussian elimination of [A | b] on the accumulators of ONE wave + back substitution: the content of
+// cublasSgetrfBatched(PivotArray = NULL) + cublasSgetrsBatched (als.cu:77,98 / 146,166).  Panels of four pivots
+// p0 .. p0 + 3 (block row Ip, lane group q); rounds 2-3 ran every panel's rank-4 update on all live tiles with fp32 MFMAs
+// (lu_wave, and a software-pipelined form of it: profiles/r04/lu_wave_serial_and_pipelined.hip.txt).
+// ----------------------------------------------------------------------------------
+struct LuLane {  // loop-invariant lane constants
+  int c, kk;
+  bool k1, k2, k3;
+  float e1c, e2c, e3c;
+};
+template <int NB, int Ip>
+__host__ __device__ constexpr int lu_prep_steps() { return 2 * (NB - Ip) + 8; }
+
+// ----------------------------------------------------------------------------------
+// The elimination BLOCKED by block rows (round 4: lu_wave_blocked, the LU the wave kernels run).  Measured on this part
+// (tools/issue_probe3.hip, profiles/r04/issue_probe3.txt): v_mfma_f32_16x16x4_f32 takes 36 cycles and does NOT run beside
+// VALU work -- neither of its own wave nor of the partner wave (8 MFMAs + 48 v_fma: 611 cycles against 293 + 379) -- so the
+// 333 rank-4 updates of the panel-serial form (12 k cycles) simply add to its ~2 200 VALU instructions (10 k): 21.5 k cycles
+// per system, which is what the Theta side showed, and why interleaving them inside the wave bought 1 %.  The bf16 MFMA is
+// different: 20 cycles for K = 16 or 32 and VALU work runs in its shadow (8 MFMAs + 48 v_fma: 335 cycles against 166 + 362).
+// So only what the NEXT panel of the same block row needs stays on the fp32 pipe, and everything below the block row waits
+// for the block row to finish:
+//   per panel (four pivots)  eliminated rows u_k as before, scaled to w_k = u_k / sqrt(u_kk) (v_rsq_f32), and ONE rank-4
+//                            fp32 MFMA per tile of the block row itself: 109 of them instead of 333;
+//   per block row            the four w of every feature block below it, split exactly into three bf16 terms (the split
+//                            of the Gram pass), and the rank-16 update of every tile below the block row as six
+//                            v_mfma_f32_16x16x16_bf16 (hh, hm, mh, mm, hl, lh: 24-bit products, fp32 accumulation).  K slot
+//                            (lane group g, element e) = pivot 4 e + g of the block row: exactly where w of panel e sits,
+//                            no data movement.  Both operands are the same w: the accumulators hold -A (negated once, with
+//                            the diagonal term) so that the update is the positive product w_k[i] w_k[j].
+// Cholesky-like scaling, LU-like pivots: u_kk > 0 for the positive definite systems of ALS; an all-zero system gives NaN as
+// the reference's unpivoted LU does.  Parity is by tolerance (the order of operations differs from the oracle's).
+// What it bought (profiles/r04/lu_parts.txt, lu_three_way_ab.txt): the solve alone 4.55 -> 4.25 ms per Netflix Theta pass
+// (480 189 systems), Theta side at f = 64 6.30 -> 5.87 ms, at f = 100 10.9 -> 10.8 ms (inside the box-to-box noise): a fused
+// half-iteration costs the SUM of its Gram pass and its solve -- both phases are bound by VALU-type issue slots (an MFMA is
+// one), so a wave in its Gram phase and its SIMD partner in the LU do not hide each other.
+// ----------------------------------------------------------------------------------
+template <int NB>
+struct LuPrepS {  // state of one panel's preparation
+  float R[NB][4];  // raw panel rows of -A at this lane's columns (ds_bpermute from lane group q)
+  float n0, n1, n2, n3;      // this lane's column of the panel's four rows of the diagonal tile (the pivot block in the quad 4 q .. 4 q + 3)
+  float rs0, rs1, rs2, rs3;  // 1 / sqrt(u_kk), quad-uniform
+  float t0, t1, t2;          // multipliers: quad lane i holds m_i0, m_i1, m_i2
+  float e0, e1, e2, rsk;     // row kk of E and 1 / sqrt(u_kk) of this lane group's pivot (after the broadcast)
+};
+struct LuLaneS : LuLane {
+  bool j1, j2, j3, j0;  // position in the quad: (c & 3) >= 1, >= 2, == 3, == 0
+  float d1, d2;         // unit diagonal of E seen from the quad: (c & 3) == 1, == 2
+};
+
+// value of quad lane I in all four lanes of every quad (DPP quad_perm [I, I, I, I])
+template <int I>
+__device__ __forceinline__ float quad_bcast(float v) {
+  // bound_ctrl set: lets the compiler fold the move into the consuming VOP1 / VOP2 instruction (v_rsq_f32_dpp, v_fmac_f32_dpp)
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), I * 0x55, 0xf, 0xf, true));
+}
+
+// acc + (quad lane I of t) * n as ONE v_fmac_f32_dpp (the compiler's DPP combiner leaves the tied-operand fmac alone and emits
+// v_mov_b32_dpp + v_fmac).  Inline asm is opaque to the hazard recogniser, so the two wait states a DPP read needs behind a
+// VALU write of the same register are spelled out (s_nop 1).
+template <int I>
+__device__ __forceinline__ float fma_quad_bcast(float t, float n, float acc) {
+  static_assert(I >= 0 && I < 4, "quad lane");
+  if constexpr (I == 0) asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(t), "v"(n));
+  if constexpr (I == 1) asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(t), "v"(n));
+  if constexpr (I == 2) asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(t), "v"(n));
+  if constexpr (I == 3) asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(t), "v"(n));
+  return acc;
+}
+
+// Micro-step STEP of the preparation of panel (Ip, q) on the negated system N = -A; w[b]: w of this panel at block b, wm:
+// w[Ip] masked to the rows below the pivot (the A operand of the block row's own update).
+// Round 4: the 4 x 4 pivot block is eliminated WHERE IT IS -- quad lanes 4 q .. 4 q + 3 of lane group q hold its columns in
+// registers 0..3 of the diagonal tile -- by every lane on its own column with DPP quad broadcasts: N_ij += (N_0i / u_00) N_0j
+// etc.  No v_readlane (10 + 7 v_mov per panel), no wave-uniform scalar chain; the rows of E and 1 / sqrt(u_kk) come out in
+// quad lane kk and reach lane group kk with four ds_bpermute.  ~30 VALU per panel instead of ~66.
+template <int NB, int Ip, int q, bool DYN, int STEP>
+__device__ __forceinline__ void lu_prep_step_s(const f32x4 (&acc)[NB * (NB + 1) / 2], LuPrepS<NB>& s, float (&w)[NB], float& wm,
+                                               float* rdiag, int f, const LuLaneS& ln) {
+  constexpr int L = NB - Ip;
+  constexpr int SD = tile_of<NB>(Ip, Ip);
+  constexpr int p0 = 16 * Ip + 4 * q;
+  auto sel = [](bool p, float a, float b) { return p ? a : b; };
+  auto rsq = [](float d) { return __builtin_amdgcn_rsqf(d); };
+  auto bperm = [](int addr, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
+  };
+  const bool v1 = !DYN || p0 + 1 < f, v2 = !DYN || p0 + 2 < f, v3 = !DYN || p0 + 3 < f;
+  if constexpr (STEP == 0) {
+    s.n0 = acc[SD][0], s.n1 = acc[SD][1], s.n2 = acc[SD][2], s.n3 = acc[SD][3];
+    s.rs0 = rsq(-quad_bcast<0>(s.n0));
+    s.t0 = s.n0 * (s.rs0 * s.rs0);  // quad lane i: m_i0 = N_0i / u_00
+    s.n1 = fma_quad_bcast<1>(s.t0, s.n0, s.n1);
+    s.n2 = fma_quad_bcast<2>(s.t0, s.n0, s.n2);
+    s.n3 = fma_quad_bcast<3>(s.t0, s.n0, s.n3);
+  } else if constexpr (STEP <= L) {
+    constexpr int b = Ip + STEP - 1;
+    constexpr int t = tile_of<NB>(Ip, b);
+    const int src = 4 * (16 * q + ln.c);  // byte address of lane (q, c)
+    // (the element goes through a float first: __builtin_bit_cast applied to a vector-element lvalue reads element 0)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float d = acc[t][r] + reg;  // lambda * n_u on the diagonal (als.cu:545-557)
-      acc[t][r] = sel(4 * kk + r == c, d, acc[t][r]);
+      const float v = acc[t][r];
+      s.R[b][r] = bperm(src, v);
+    }
+  } else if constexpr (STEP == L + 1) {
+    const float d = -quad_bcast<1>(s.n1);
+    s.rs1 = rsq(DYN ? sel(v1, d, 1.0f) : d);
+    s.t1 = s.n1 * (s.rs1 * s.rs1);
+    s.n2 = fma_quad_bcast<2>(s.t1, s.n1, s.n2);
+    s.n3 = fma_quad_bcast<3>(s.t1, s.n1, s.n3);
+  } else if constexpr (STEP == L + 2) {
+    const float d = -quad_bcast<2>(s.n2);
+    s.rs2 = rsq(DYN ? sel(v2, d, 1.0f) : d);
+    s.t2 = s.n2 * (s.rs2 * s.rs2);
+    s.n3 = fma_quad_bcast<3>(s.t2, s.n2, s.n3);
+  } else if constexpr (STEP == L + 3) {
+    const float d = -quad_bcast<3>(s.n3);
+    s.rs3 = rsq(DYN ? sel(v3, d, 1.0f) : d);
+    // multipliers that exist: m_i0 for i >= 1, m_i1 for i >= 2, m_32
+    s.t0 = sel(ln.j1, s.t0, 0.f);
+    s.t1 = sel(ln.j2, s.t1, 0.f);
+    s.t2 = sel(ln.j3, s.t2, 0.f);
+  } else if constexpr (STEP == L + 4) {
+    // rows of E = (unit lower triangle of the panel)^-1 in the quad: lane kk holds E[kk][0..2]
+    const float a = fma_quad_bcast<1>(s.t0, s.t1, s.t0);           // lane 1: m10, lane 2: e20, lane 3: m31 m10 + m30
+    s.e0 = sel(ln.j0, 1.0f, fma_quad_bcast<2>(a, s.t2, a));          // lane 3: m32 e20 + m31 m10 + m30 = e30
+    s.e1 = fma_quad_bcast<2>(s.t1, s.t2, s.t1) + ln.d1;              // lane 1: 1, lane 2: m21, lane 3: m32 m21 + m31 = e31
+  } else if constexpr (STEP == L + 5) {
+    s.e2 = s.t2 + ln.d2;                                              // lane 2: 1, lane 3: m32
+    float rsk = sel(ln.j3, s.rs3, sel(ln.j2, s.rs2, sel(ln.j1, s.rs1, s.rs0)));
+    if constexpr (DYN) rsk = sel(p0 + (ln.c & 3) < f, rsk, 0.f);  // a pivot past f (short last panel) eliminates nothing
+    s.rsk = rsk;
+  } else if constexpr (STEP == L + 6) {
+    // quad lane kk of lane group q -> every lane of lane group kk
+    const int src = 4 * (20 * q + ln.kk);
+    s.e0 = bperm(src, s.e0);
+    s.e1 = bperm(src, s.e1);
+    s.e2 = bperm(src, s.e2);
+    s.rsk = bperm(src, s.rsk);
+  } else if constexpr (STEP == L + 7) {
+    // the back substitution runs on the rows of -U that stay in the accumulators: it wants 1 / (-u_kk) (all 16 lanes of
+    // a group write the same value to the same word; p0 + kk < (f + 3) & ~3 always, a pivot past f is never read)
+    rdiag[p0 + ln.kk] = -(s.rsk * s.rsk);
+  } else {
+    constexpr int b = Ip + STEP - (L + 8);
+    const float un = fmaf(ln.e3c, s.R[b][3], fmaf(s.e2, s.R[b][2], fmaf(s.e1, s.R[b][1], s.e0 * s.R[b][0])));  // -u_k at block b
+    w[b] = un * s.rsk;  // the sign is immaterial: w meets itself
+    if constexpr (b == Ip) wm = sel(ln.c > 4 * q + ln.kk, w[b], 0.f);  // rows at or above the pivot stay
+  }
+}
+
+// exact three-way split of (a, b) into packed bf16 pairs (a in the low half), as split_micro does for the gathered rows
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned& H, unsigned& M, unsigned& Lw) {
+  H = pack_bf16(a, b);
+  const float ra = sub_bf16_lo(a, H), rb = sub_bf16_hi(b, H);
+  M = pack_bf16(ra, rb);
+  const float ta = sub_bf16_lo(ra, M), tb = sub_bf16_hi(rb, M);
+  Lw = pack_bf16(ta, tb);
+}
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma_bf16_k16(u32x2 a, u32x2 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(bf16x4, a), __builtin_bit_cast(bf16x4, b), c, 0, 0, 0);
+}
+
+// n-th tile (row-major) of the part of the upper triangle below block row I0: rows I0 .. NB - 1
+template <int NB, int I0>
+__host__ __device__ constexpr int lu_trailing_tile(int n) {
+  for (int I = I0; I < NB; ++I) {
+    if (n < NB - I) return tile_of<NB>(I, I + n);
+    n -= NB - I;
+  }
+  return -1;
+}
+// product PROD (small terms first, as in the Gram pass) of the rank-16 bf16 update of tile t
+template <int NB, int t, int PROD>
+__device__ __forceinline__ void lu_trailing_mfma(f32x4 (&acc)[NB * (NB + 1) / 2], const u32x2 (&h)[NB], const u32x2 (&m)[NB],
+                                                 const u32x2 (&l)[NB]) {
+  constexpr int I = tile_I<NB>(t), J = tile_J<NB>(t);
+  if constexpr (PROD == 0) acc[t] = mfma_bf16_k16(l[I], h[J], acc[t]);
+  if constexpr (PROD == 1) acc[t] = mfma_bf16_k16(h[I], l[J], acc[t]);
+  if constexpr (PROD == 2) acc[t] = mfma_bf16_k16(m[I], m[J], acc[t]);
+  if constexpr (PROD == 3) acc[t] = mfma_bf16_k16(m[I], h[J], acc[t]);
+  if constexpr (PROD == 4) acc[t] = mfma_bf16_k16(h[I], m[J], acc[t]);
+  if constexpr (PROD == 5) acc[t] = mfma_bf16_k16(h[I], h[J], acc[t]);
+}
+
+template <int NB, int FC>
+__device__ __forceinline__ float lu_wave_blocked(f32x4 (&acc)[NB * (NB + 1) / 2], float* T, int f_rt, float reg,
+                                                 float* __restrict__ x_global, int lane, int dbg = 0) {
+  constexpr int NT = NB * (NB + 1) / 2;
+  const int f = FC ? FC : f_rt;
+  LuLaneS ln;
+  ln.c = lane & 15;
+  ln.kk = (lane >> 4) & 3;
+  ln.k1 = ln.kk == 1, ln.k2 = ln.kk == 2, ln.k3 = ln.kk == 3;
+  ln.e1c = ln.k1 ? 1.0f : 0.f, ln.e2c = ln.k2 ? 1.0f : 0.f, ln.e3c = ln.k3 ? 1.0f : 0.f;  // unit diagonal of E
+  ln.j0 = (lane & 3) == 0, ln.j1 = (lane & 3) >= 1, ln.j2 = (lane & 3) >= 2, ln.j3 = (lane & 3) == 3;
+  ln.d1 = (lane & 3) == 1 ? 1.0f : 0.f, ln.d2 = (lane & 3) == 2 ? 1.0f : 0.f;
+  // the system, negated: -(A + lambda n_u I) (als.cu:545-557 for the diagonal term)
+  static_for<NT>([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    constexpr bool diag = tile_I<NB>(t) == tile_J<NB>(t);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = acc[t][r];
+      if constexpr (diag) v = (4 * ln.kk + r == ln.c) ? v + reg : v;
+      acc[t][r] = -v;
     }
   });
   float* rdiag = T + 16 * NB * kBsPitch;  // pivot reciprocals, then 16 zeros (rows outside a pivot block read these)
   float* zpad = rdiag + ((f + 3) & ~3);
   if (lane < 16) zpad[lane] = 0.f;
 
-  auto bperm = [](int addr, float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
-  };
-
+  LuPrepS<NB> s;
+  // bf16 planes of the w of the block row that has just been eliminated (blocks below it): the operands of its rank-16
+  // update.  The tiles of the NEXT block row get theirs at once (its panels read them); the tiles below that are updated
+  // ONE MFMA AT A TIME IN FRONT OF THE MICRO-STEPS of the next block row's panels: a bf16 MFMA runs beside the VALU work
+  // of its own wave only when the two alternate in program order (in-order issue), and the partner wave covers but a
+  // third of a burst (measured: the update in one burst per block row costs 0.92 ms of the Theta side's 4.6 ms solve).
+  u32x2 h[NB], m[NB], l[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) h[b] = m[b] = l[b] = u32x2{0u, 0u};
   static_for<NB>([&](auto ipc) {
     constexpr int Ip = decltype(ipc)::value;
-    constexpr int SD = tile_of<NB>(Ip, Ip);
+    constexpr int L = NB - Ip;
+    // pending: block row Ip - 1's update of the tiles below block row Ip
+    constexpr int NTl = Ip >= 1 ? (L - 1) * L / 2 : 0;  // tiles of rows Ip + 1 .. NB - 1
+    constexpr int TP = 6 * NTl;
+    constexpr int S = lu_prep_steps<NB, Ip>();
+    float w[4][NB];  // w[e][b]: panel e of this block row at feature block b >= Ip
     static_for<4>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
       constexpr int p0 = 16 * Ip + 4 * q;
-      if (p0 < f) {  // wave-uniform (compile-time when FC != 0)
-        // 2a. raw panel rows of lane group q to every lane group (ds_bpermute: no LDS memory), issued
-        // first: their latency hides behind the pivot chain
-        const int src = 4 * (16 * q + c);  // byte address of lane (q, c)
-        float R[NB][4];
-        static_for<NB>([&](auto bc) {
-          constexpr int b = decltype(bc)::value;
-          if constexpr (b >= Ip) {
-            constexpr int t = tile_of<NB>(Ip, b);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) R[b][r] = bperm(src, acc[t][r]);
-          }
-        });
-        // 1. pivot block: rows = registers 0..3 of lane group q, columns = lanes 4 q .. 4 q + 3 of it
-        constexpr int l0 = 20 * q;
-        const bool v1 = p0 + 1 < f, v2 = p0 + 2 < f, v3 = p0 + 3 < f;
-        const bool vk = p0 + kk < f;  // this lane group's pivot exists (short last panel otherwise)
-        // v_readlane: measured faster than a wave-uniform ds_bpermute broadcast (Theta side 12.8 vs 13.3 ms):
-        // a DS instruction holds the wave's issue slot twice as long as a VALU one
-        auto bc = [&](float v, int l) {
-          return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-        };
-        float P00 = bc(acc[SD][0], l0), P01 = bc(acc[SD][0], l0 + 1), P02 = bc(acc[SD][0], l0 + 2),
-              P03 = bc(acc[SD][0], l0 + 3);
-        float P11 = bc(acc[SD][1], l0 + 1), P12 = bc(acc[SD][1], l0 + 2), P13 = bc(acc[SD][1], l0 + 3);
-        float P22 = bc(acc[SD][2], l0 + 2), P23 = bc(acc[SD][2], l0 + 3);
-        float P33 = bc(acc[SD][3], l0 + 3);
-        auto recip = [](float d) { return __builtin_amdgcn_rcpf(d); };
-        const float rp0 = recip(P00);
-        const float m10 = -P01 * rp0, m20 = -P02 * rp0, m30 = -P03 * rp0;
-        P11 = fmaf(m10, P01, P11);
-        P12 = fmaf(m10, P02, P12);
-        P13 = fmaf(m10, P03, P13);
-        P22 = fmaf(m20, P02, P22);
-        P23 = fmaf(m20, P03, P23);
-        P33 = fmaf(m30, P03, P33);
-        const float rp1 = recip(sel(v1, P11, 1.0f));
-        const float m21 = -P12 * rp1, m31 = -P13 * rp1;
-        P22 = fmaf(m21, P12, P22);
-        P23 = fmaf(m21, P13, P23);
-        P33 = fmaf(m31, P13, P33);
-        const float rp2 = recip(sel(v2, P22, 1.0f));
-        const float m32 = -P23 * rp2;
-        P33 = fmaf(m32, P23, P33);
-        const float rp3 = recip(sel(v3, P33, 1.0f));
-        const float e20 = fmaf(m21, m10, m20);
-        const float e31 = fmaf(m32, m21, m31);
-        const float e30 = fmaf(m32, e20, fmaf(m31, m10, m30));
-        const float rpk = sel(k3, rp3, sel(k2, rp2, sel(k1, rp1, rp0)));
-        // row kk of E = (unit lower triangle of the panel)^-1: eliminated row kk = sum_j E[kk][j] raw_j
-        const float e0 = sel(k3, e30, sel(k2, e20, sel(k1, m10, 1.0f)));
-        const float e1 = sel(k3, e31, sel(k2, m21, e1c));
-        const float e2 = sel(k3, m32, e2c);
-        const float nrp = sel(vk, -rpk, 0.f);
-        // 2. eliminated panel row of this lane group at every live block (the broadcasts were issued
-        // ahead of the pivot chain)
-        float ub[NB];
-        static_for<NB>([&](auto bc) {
-          constexpr int b = decltype(bc)::value;
-          if constexpr (b >= Ip) {
-            ub[b] = fmaf(e3c, R[b][3], fmaf(e2, R[b][2], fmaf(e1, R[b][1], e0 * R[b][0])));
-          }
-        });
-        // 4. the eliminated rows stay in the accumulators (the update below leaves rows at and above a
-        // pivot alone); only the pivot reciprocals go to LDS, for the back substitution
-        if (c == 4 && vk) rdiag[p0 + kk] = rpk;
-        // 3. rank-4 update of the live tiles; block row Ip (which holds the next panel) first so
-        // that the next pivot chain can start while the rest of the update drains
-        static_for<NB>([&](auto i2) {
-          constexpr int I = decltype(i2)::value;
-          if constexpr (I >= Ip) {
-            float la = ub[I] * nrp;
-            if constexpr (I == Ip) la = sel(c > 4 * q + kk, la, 0.f);  // rows at or above the pivot stay
-            static_for<NB>([&](auto j2) {
-              constexpr int J = decltype(j2)::value;
-              if constexpr (J >= I) {
-                constexpr int t = tile_of<NB>(I, J);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(la, ub[J], acc[t], 0, 0, 0);
-              }
-            });
-          }
-        });
-#if !(CUMF_WAVE_VARIANT & 1)
-        // no instruction motion across panels: left free, the scheduler hoists the next panels' broadcasts
-        // until the accumulators spill (measured: Theta side 13.3 -> 12.3 ms with the barrier)
-        __builtin_amdgcn_sched_barrier(0);
+      constexpr bool last_row = Ip == NB - 1;
+      constexpr bool exists_static = !last_row || (FC != 0 && p0 < FC);
+      constexpr bool dyn = last_row && FC == 0;
+      auto panel = [&]() {
+        float wm = 0.f;
+#if CUMF_ABLATE
+        // profiling build: 256 = no panel preparation (constants instead), 512 = no fp32 MFMAs
+        if (dbg & 256) {
+          static_for<L>([&](auto bc2) { w[q][Ip + decltype(bc2)::value] = acc[tile_of<NB>(Ip, Ip + decltype(bc2)::value)][q]; });
+          wm = w[q][Ip];
+        } else
 #endif
+        static_for<S>([&](auto sc) {
+          constexpr int i = decltype(sc)::value;
+          constexpr int gs = q * S + i;  // micro-step of the block row
+          // pending MFMAs n in [gs TP / 4S, (gs + 1) TP / 4S): product-major, consecutive ones hit different tiles
+          constexpr int n0 = gs * TP / (4 * S), n1 = (gs + 1) * TP / (4 * S);
+          static_for<n1 - n0>([&](auto nc) {
+            constexpr int n = n0 + decltype(nc)::value;
+            lu_trailing_mfma<NB, lu_trailing_tile<NB, Ip + 1>(n % NTl), n / NTl>(acc, h, m, l);
+          });
+          lu_prep_step_s<NB, Ip, q, dyn, i>(acc, s, w[q], wm, rdiag, f, ln);
+          if constexpr (TP > 0) __builtin_amdgcn_sched_barrier(0);
+        });
+        // the block row's own tiles: what its next panel reads (and the rows the back substitution reads later)
+#if CUMF_ABLATE
+        if (!(dbg & 512))
+#endif
+        static_for<L>([&](auto bc2) {
+          constexpr int b = Ip + decltype(bc2)::value;
+          constexpr int t = tile_of<NB>(Ip, b);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wm, w[q][b], acc[t], 0, 0, 0);
+        });
+        __builtin_amdgcn_sched_barrier(0);  // no instruction motion across panels (lu_wave: hoisted broadcasts spill)
+      };
+      if constexpr (exists_static) {
+        panel();
+      } else if constexpr (dyn) {
+        if (p0 < f) panel();  // wave-uniform
       }
     });
+#if CUMF_ABLATE
+    if (!(dbg & 1024))  // profiling build: 1024 = no trailing update
+#endif
+    if constexpr (L > 1) {
+      // planes of this block row's w; the tiles of block row Ip + 1 at once, block by block as the planes appear
+      static_for<L - 1>([&](auto bc2) {
+        constexpr int b = Ip + 1 + decltype(bc2)::value;
+        unsigned H0, M0, L0, H1, M1, L1;
+        split3_pair(w[0][b], w[1][b], H0, M0, L0);
+        split3_pair(w[2][b], w[3][b], H1, M1, L1);
+        h[b] = u32x2{H0, H1};
+        m[b] = u32x2{M0, M1};
+        l[b] = u32x2{L0, L1};
+        constexpr int t = tile_of<NB>(Ip + 1, b);
+        static_for<6>([&](auto pc) { lu_trailing_mfma<NB, t, decltype(pc)::value>(acc, h, m, l); });
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    }
   });
   __syncthreads();  // one wave: orders the rdiag writes before the reads below
-  back_substitute_tiles<NB, (16 * NB + 63) / 64>(acc, T, rdiag, zpad, f, x_global, lane);
+#if CUMF_ABLATE
+  if (dbg & 2048) {  // profiling build: no back substitution
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) sum += (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]);
+    if (lane < f) x_global[lane] = sum;
+    return sum;
+  }
+#endif
+  return back_substitute_tiles<NB, (16 * NB + 63) / 64>(acc, T, rdiag, zpad, f, x_global, lane);
 }
 
 // ----------------------------------------------------------------------------------
@@ -950,6 +1153,14 @@ __device__ __forceinline__ void cg_wave_core(f32x4 (&T)[(NB * (NB + 1) / 2 + NW 
       if (live[J]) xg[16 * J + c] = x[J];
     });
   }
+  if constexpr (NW == 1) {
+    if (a.sse_bins != nullptr) {  // fused train SSE: S - x.b - x.r - reg |x|^2 (see wave_tile_ff)
+      constexpr int NT1 = NB * (NB + 1) / 2;
+      const float S = wave_tile_ff<NB>(T[NT1 - 1], f) - reg;  // the diagonal carries reg in slot f too
+      const float xb = dot(x, b), xr = dot(x, r), xx = dot(x, x);
+      wave_sse_add(a.sse_bins, (double)S - (double)xb - (double)xr - (double)reg * (double)xx, rowlen, lane);
+    }
+  }
 }
 
 // tiles of wave W from the dumped slots (summed in slot order), then the CG
@@ -1106,7 +1317,17 @@ __global__ __launch_bounds__(64, CUMF_WAVE_MIN_WAVES) void als_wave_kernel(const
   } else if constexpr (MODE == kModeCG) {
     cg_wave_core<NB, 1, 0>(acc, smem, a, f, row, rowlen, lane);  // the reference's default solver (als.cu:28)
   } else {
-    lu_wave<NB, FC>(acc, smem, f, reg, a.update + (size_t)row * f, lane);
+#if CUMF_ABLATE
+    const float ssq = lu_wave_blocked<NB, FC>(acc, smem, f, reg, a.update + (size_t)row * f, lane, a.dbg);
+#else
+    const float ssq = lu_wave_blocked<NB, FC>(acc, smem, f, reg, a.update + (size_t)row * f, lane);
+#endif
+    constexpr float ff_sign = -1.0f;  // the blocked elimination works on the negated system
+    if (a.sse_bins != nullptr) {  // fused train SSE: (f, f) of the eliminated system - reg (1 + |theta|^2)
+      const float ff = ff_sign * wave_tile_ff<NB>(acc[NT - 1], f);
+      const float tt = wave_sum_uniform(ssq);
+      wave_sse_add(a.sse_bins, (double)ff - (double)reg * (1.0 + (double)tt), rowlen, lane);
+    }
   }
 }
 

@@ -87,6 +87,22 @@ int cumf_fused_available(int f, int solver);
 int cumf_als_update_fused(const cumf_plan_t* plan, const int* colidx, const float* val,
                           const float* gather, float* update, int f, float lambda, int solver,
                           int cg_iters, void* stream);
+/*
+ * The same half-iteration + the train SSE of the updated rows at no extra pass (replaces the RMSE kernel launch of
+ * als.cu:979-991 for the train set when it is the Theta update: the errors r - x_u . theta_v of a column only involve
+ * that column's new theta_v and the X it gathered).  The rating rides in slot f of the gathered rows, so the Gram
+ * pass also accumulates sum r^2 in entry (f, f) of the augmented system; LU turns that entry into its Schur complement
+ * sum r^2 + lambda n - b^T A^-1 b, CG supplies x.b, x.r, |x|^2: sum_u (r - x_u . t)^2 = sum r^2 - 2 t.b + t^T G t
+ * follows without reading a rating or a factor row again.  sse_bins: CUMF_SSE_BINS doubles in DEVICE
+ * memory, zeroed by the caller, ADDED to (fp64 atomics); the SSE is their sum.  Only when
+ * cumf_fused_sse_available(plan, solver): every row solved inside the wave-per-item kernel (16 <= f <= 111, gram mode
+ * not "exact", no chunked row); otherwise an error, and cumf_sse is the way.
+ */
+#define CUMF_SSE_BINS 1024
+int cumf_fused_sse_available(const cumf_plan_t* plan, int solver);
+int cumf_als_update_fused_sse(const cumf_plan_t* plan, const int* colidx, const float* val,
+                              const float* gather, float* update, int f, float lambda, int solver,
+                              int cg_iters, double* sse_bins, void* stream);
 
 /*
  * Materialising Gram + RHS (the reference's data flow): tt receives

@@ -785,3 +785,66 @@ def test_doals_tt_fp16(oracle, alslib):
                                     d["test_data"], m, n, f, r.nnz, r.nnz_test, lam, 2, 1, 1, 0, thetat_init=th0,
                                     xt_init=x0, solver="cg", exact_test_grid=True, return_log=True)
     assert not np.array_equal(th32, th_h)
+
+
+@pytest.mark.parametrize("solver", ["lu", "cg"])
+@pytest.mark.parametrize("f", [100, 96, 64, 20])
+def test_fused_train_sse_matches_the_rmse_kernel(oracle, alslib, f, solver):
+    """Round 4: the Theta update delivers the train SSE of its columns from the systems it has just solved
+    (cumf_als_update_fused_sse: entry (f, f) of the augmented Gram -- sum r^2 -- turned into its Schur complement by
+    the LU, or S - x.b - x.r - reg |x|^2 after the CG; no rating or factor row read again).  Against the RMSE kernel
+    (als.cu:191-219 restated, cumf_sse) and the oracle's fp64 sum on the same factors: relative 2e-5 (it is an
+    identity; what differs is where fp32 rounding happens -- measured 1e-7 .. 3e-6)."""
+    _need_gpu()
+    from cumf_als_amd import als
+
+    r = _dataset(900, 700, 60000, 500, seed=5)
+    d = r.numpy()
+    rg = r.to("cuda")
+    eng = als.ALSEngine(rg, f, 0.05, solver=solver)
+    eng.init_factors(_factors(r.n, f, 3))
+    for it in range(3):
+        eng.update_x()
+        fused = eng.update_theta_with_train_sse()
+        assert fused is not None
+        torch.cuda.synchronize()
+        kern = float(als.sse(rg.csr_data, rg.coo_row, rg.csr_indices, eng.thetaT, eng.XT).item())
+        ref = oracle.sse(d["csr_data"], d["coo_row"], d["csr_indices"], eng.thetaT.cpu().numpy(), eng.XT.cpu().numpy(),
+                         r.nnz, f, dtype=np.float64)
+        got = float(fused.item())
+        print(f"fused train SSE f={f} {solver} iter {it}: fused {got:.6f} kernel {kern:.6f} oracle64 {ref:.6f}  "
+              f"rel {abs(got - kern) / kern:.2e} / {abs(got - ref) / ref:.2e}")
+        assert abs(got - kern) <= 2e-5 * kern and abs(got - ref) <= 2e-5 * ref, (got, kern, ref)
+
+
+def test_doals_rmse_log_fused_vs_kernel(alslib):
+    """doALS with the train RMSE taken from the Theta update (default) and from the RMSE kernel (CUMF_ALS_RMSE=kernel,
+    the reference's data flow als.cu:966-991): the logs agree to 2e-6 and the factors are bit-identical (the fused SSE
+    only reads what the solver leaves behind)."""
+    _need_gpu()
+    import os
+
+    from cumf_als_amd import als
+
+    m, n, nnz, nnz_test, f, lam = 1200, 900, 90000, 4000, 100, 0.05
+    r = _dataset(m, n, nnz, nnz_test, seed=8)
+    d = r.numpy()
+    th0 = _factors(n, f, 2)
+
+    def run(solver):
+        return als.do_als(d["csr_indptr"], d["csr_indices"], d["csr_data"], d["csc_indices"], d["csc_indptr"], d["csc_data"],
+                          d["coo_row"], d["test_row"], d["test_col"], d["test_data"], m, n, f, r.nnz, r.nnz_test, lam, 4, 1, 2,
+                          0, thetat_init=th0, solver=solver, return_log=True)
+
+    for solver in ("lu", "cg"):
+        th_a, x_a, rm_a, log_a = run(solver)
+        os.environ["CUMF_ALS_RMSE"] = "kernel"
+        try:
+            th_b, x_b, rm_b, log_b = run(solver)
+        finally:
+            del os.environ["CUMF_ALS_RMSE"]
+        np.testing.assert_array_equal(th_a, th_b)
+        np.testing.assert_array_equal(x_a, x_b)
+        print(f"doALS {solver}: fused log {log_a[:, 0].tolist()} kernel log {log_b[:, 0].tolist()}")
+        assert np.abs(log_a - log_b).max() <= 2e-6 * max(1.0, np.abs(log_b).max()), (log_a, log_b)
+        assert rm_a == rm_b
