@@ -106,6 +106,7 @@ struct PlanLists {
   const long long* w_begin;
   float* part2;      // dense-slot tile buffer of the batched path (lazily allocated), part2_rows slots
   long part2_rows;
+  double chunk_share;  // share of the plan's ratings that sits in chunked rows
 };
 hipError_t launch_half_iteration(const KernelArgs& a, int mode, long n_items, long n_mrows, hipStream_t stream,
                                  const PlanLists* lists = nullptr);

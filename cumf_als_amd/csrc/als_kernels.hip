@@ -591,9 +591,6 @@ __device__ __forceinline__ void lu_solve_reg(Load load, float* __restrict__ U, i
     for (int kk = 0; kk < 16; ++kk) {
       const int k = 16 * kb + kk;
       if (k >= f) break;
-#if CUMF_VARIANT_A & 32
-      if (k >= 0) break;
-#endif
       float* urow = blk + kk * pitch;
       if (ti == kk) {
         float* w = urow + tj;
@@ -613,20 +610,14 @@ __device__ __forceinline__ void lu_solve_reg(Load load, float* __restrict__ U, i
           rdiag[k] = fmaf(fmaf(-piv, t, 1.0f), t, t);  // one Newton step: 1/pivot to ~1 ulp
         }
       }
-#if !(CUMF_VARIANT_A & 4)
       __syncthreads();
-#endif
       float ui[NB], uj[NB];
       const float nrp = -rdiag[k];
       static_for<NB>([&](auto bc) {
         constexpr int b = decltype(bc)::value;
         if constexpr (b >= kb) {
           uj[b] = urow[16 * b + tj];
-#if CUMF_VARIANT_A & 1
-          ui[b] = uj[b];
-#else
           ui[b] = urow[16 * b + ti];
-#endif
         }
       });
       static_for<NB>([&](auto bc) {
@@ -638,19 +629,13 @@ __device__ __forceinline__ void lu_solve_reg(Load load, float* __restrict__ U, i
         constexpr int bi = decltype(bic)::value;
         static_for<NB>([&](auto bjc) {
           constexpr int bj = decltype(bjc)::value;
-#if CUMF_VARIANT_A & 2
-          if constexpr (bi >= kb && bj == bi) a[bi][bj] = fmaf(ui[bi], uj[bj], a[bi][bj]);
-#else
           if constexpr (bi >= kb && bj >= bi) a[bi][bj] = fmaf(ui[bi], uj[bj], a[bi][bj]);
-#endif
         });
       });
     }
   });
   __syncthreads();
-#if !(CUMF_VARIANT_A & 8)
   if (tid < 64) back_substitute_zeroed<NB, (16 * NB + 63) / 64>(U, f, rdiag, zpad, x_global, tid);
-#endif
 }
 
 // LDS floats of the fused LU of NB feature blocks: lu_solve_mfma (NB >= 7) or the thread-grid
@@ -1612,9 +1597,30 @@ hipError_t launch_half_iteration(const KernelArgs& a, int mode, long n_items, lo
     hipError_t e = hipSuccess;
     KernelArgs aw = a;
     aw.whole_only = n_mrows == 0;  // no chunked row in the plan: every item is a whole row
+    // A plan with a FEW chunked rows (a Theta side with a handful of very long columns): their chunk items go first, in a
+    // launch of their own, and the whole rows keep the instance without the dump exit (no spilled accumulators, VERDICT r03
+    // weak 7).  When the chunks are most of the work (the Netflix X side: 86 % of the ratings) one combined launch stays:
+    // the whole rows fill the tail of the equal-sized chunk items, worth more than the spills cost.
+    KernelArgs ac = a;
+    long n_chunk_first = 0;
+    if (mode == kModeLU && n_mrows > 0 && lists != nullptr && lists->n_citems > 0 && lists->n_witems > 0 &&
+        lists->chunk_share < 0.25) {  // (LU: the only mode with an instance for whole rows alone)
+      n_chunk_first = lists->n_citems;
+      ac.item_row = lists->c_row, ac.item_begin = lists->c_begin, ac.item_len = lists->c_len;
+      ac.item_slot = lists->c_slot, ac.item_rowlen = lists->c_rowlen;
+      ac.whole_only = 0;
+      aw.item_row = lists->w_row, aw.item_begin = lists->w_begin, aw.item_len = lists->w_len;
+      aw.item_slot = nullptr, aw.item_rowlen = lists->w_rowlen;
+      aw.whole_only = 1;
+      n_items = lists->n_witems;
+    }
     switch (nb_for_f(a.f)) {
 #define CUMF_WAVE(N)                                              \
   case N:                                                         \
+    if (n_chunk_first > 0) {                                      \
+      e = wave_item_launch<N>(ac, mode, n_chunk_first, stream);   \
+      if (e != hipSuccess) return e;                              \
+    }                                                             \
     e = wave_item_launch<N>(aw, mode, n_items, stream);           \
     if (e != hipSuccess) return e;                                \
     if (g_timing) (void)hipEventRecord(g_ev[1], stream);          \

@@ -5,9 +5,6 @@
 
 namespace cumf {
 
-#ifndef CUMF_VARIANT_A
-#define CUMF_VARIANT_A 0  // ablation switches of tools/lu_variants.sh (timing experiments; results are wrong)
-#endif
 
 // Tile t of the upper triangle lives in accumulator slot t / NW of wave role t % NW: every role keeps a
 // similar share of live tiles all through the elimination.
@@ -216,9 +213,6 @@ __device__ __forceinline__ void lu_solve_mfma(LuAcc<NB, NW>& acc, float* __restr
     for (int q = 0; q < 4; ++q) {
       const int p0 = 16 * Ip + 4 * q;
       if (p0 >= f) break;
-#if CUMF_VARIANT_A & 32
-      if (p0 >= 0) break;
-#endif
       // 1. publish the raw panel rows (tiles of block row Ip, lane group q)
       static_for<TPW>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
@@ -310,12 +304,7 @@ __device__ __forceinline__ void lu_solve_mfma(LuAcc<NB, NW>& acc, float* __restr
           const float own = rkp[16 * b + c];
           const float a0 = r0p[16 * b + c], a1 = r1p[16 * b + c], a2 = r2p[16 * b + c];
           // lanes of a pivot past f (short last panel) keep a finite dummy: their A operand is 0
-#if CUMF_VARIANT_A & 64
-          ub[b] = own + c0 + c1 + c2;
-          (void)a0; (void)a1; (void)a2;
-#else
           ub[b] = fmaf(c2, a2, fmaf(c1, a1, fmaf(c0, a0, own)));
-#endif
         }
       });
       // 3. rank-4 update of the live tiles
@@ -327,11 +316,7 @@ __device__ __forceinline__ void lu_solve_mfma(LuAcc<NB, NW>& acc, float* __restr
           if constexpr (I >= Ip) {
             float la = ub[I] * nrp;
             if constexpr (I == Ip) la = (c > 4 * q + kk) ? la : 0.f;  // rows at or above the pivot stay
-#if CUMF_VARIANT_A & 2
-            acc[s][0] += la * ub[J];
-#else
             acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(la, ub[J], acc[s], 0, 0, 0);
-#endif
           }
         }
       });
@@ -340,9 +325,7 @@ __device__ __forceinline__ void lu_solve_mfma(LuAcc<NB, NW>& acc, float* __restr
   });
   // the eliminated rows stay in the accumulators (the masked update leaves rows at and above a pivot alone)
   __syncthreads();  // rdiag is complete
-#if !(CUMF_VARIANT_A & 8)
   back_substitute_tiles_wg<NB, W, (16 * NB + 63) / 64, NW>(acc, Twin, rdiag, zpad, f, x_global, lane);
-#endif
 }
 
 }  // namespace cumf

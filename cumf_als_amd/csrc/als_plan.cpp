@@ -34,6 +34,7 @@ struct cumf_plan {
   long rows = 0, row_begin = 0, row_end = 0;
   int f = 0, nb = 0, chunk = 0;
   long long plan_nnz = 0;  // ratings of the planned rows
+  long long chunk_nnz = 0;  // ... of which in chunked rows
   long n_items = 0, n_slots = 0, n_mrows = 0;
   int* d_item_row = nullptr;
   long long* d_item_begin = nullptr;
@@ -213,6 +214,7 @@ extern "C" int cumf_plan_create(cumf_plan_t** out, const void* rowptr_host, int 
   PLAN_CHECK(upload(&p->d_mrow_nslots, mrow_nslots));
   PLAN_CHECK(upload(&p->d_mrow_rowlen, mrow_rowlen));
   p->n_citems = (long)c_row.size();
+  for (int len : c_len) p->chunk_nnz += len;
   p->n_witems = (long)w_row.size();
   PLAN_CHECK(upload(&p->d_c_row, c_row));
   PLAN_CHECK(upload(&p->d_c_begin, c_begin));
@@ -361,7 +363,7 @@ int plan_lists(const cumf_plan_t* p, PlanLists* out, hipStream_t stream, bool ne
   }
   *out = PlanLists{p->n_items,  p->n_mrows, p->n_citems, p->n_witems, p->d_c_row,    p->d_c_len,  p->d_c_slot,
                    p->d_c_rowlen, p->d_c_begin, p->d_w_row,  p->d_w_len,  p->d_w_rowlen, p->d_w_begin, part2,
-                   rows};
+                   rows,          p->plan_nnz > 0 ? (double)p->chunk_nnz / (double)p->plan_nnz : 0.0};
   return 0;
 }
 
@@ -545,18 +547,19 @@ int update_fused_impl(const cumf_plan_t* p, const int* colidx, const float* val,
   const int mode = (solver == CUMF_SOLVER_LU) ? kModeLU : kModeCG;
   PlanLists lists{};
   const bool batched = wave_batched_path(f, mode);
-  if (batched) {
+  {
     // whole rows are solved inside the two-wave Gram kernel (CG always, LU up to NB = 9); only the larger LUs
-    // go through the dense-slot tile buffer
-    const int rc = plan_lists(p, &lists, static_cast<hipStream_t>(stream), mode == kModeLU && p->nb > kMaxFusedLuWaveNB);
+    // go through the dense-slot tile buffer.  The one-wave kernels (f <= 111) use the lists to launch the few chunk
+    // items of a plan apart from its whole rows (launch_half_iteration).
+    const int rc = plan_lists(p, &lists, static_cast<hipStream_t>(stream),
+                              batched && mode == kModeLU && p->nb > kMaxFusedLuWaveNB);
     if (rc) return rc;
   }
   if (gram_mode() == kGramFast && (batched || wave_path_available(f, mode))) {
     const int rc = fast_words(p, gather, f, static_cast<hipStream_t>(stream), &a);
     if (rc) return rc;
   }
-  CUMF_HIP_CHECK(launch_half_iteration(a, mode, p->n_items, p->n_mrows, static_cast<hipStream_t>(stream),
-                                       batched ? &lists : nullptr));
+  CUMF_HIP_CHECK(launch_half_iteration(a, mode, p->n_items, p->n_mrows, static_cast<hipStream_t>(stream), &lists));
   return 0;
 }
 }  // namespace

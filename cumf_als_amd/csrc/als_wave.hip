@@ -60,9 +60,6 @@ typedef __attribute__((address_space(3))) float* lds_float_ptr;  // LDS pointer 
 #ifndef CUMF_WAVE_NB
 #error "compile with -DCUMF_WAVE_NB=<feature blocks>"
 #endif
-#ifndef CUMF_WAVE_VARIANT
-#define CUMF_WAVE_VARIANT 0  // A/B switches (tools/wave_variants.sh): 1 = LU without the per-panel scheduling barrier, 2 = no f == 100 instance, 8 = one wave per SIMD
-#endif
 
 constexpr int kWaveStage = 32;   // ratings per stage = K of v_mfma_f32_16x16x32_bf16
 constexpr int kZeroFloats = 256; // >= 16 * kMaxWaveNB + 16
@@ -1215,11 +1212,7 @@ __global__ __launch_bounds__(64 * NW, 2) void als_wave_cg_kernel(const KernelArg
 // ----------------------------------------------------------------------------------
 // Kernel: one 64-thread workgroup (= one wave) per plan item.  FC != 0: f known at compile time.
 // ----------------------------------------------------------------------------------
-#if CUMF_WAVE_VARIANT & 8
-#define CUMF_WAVE_MIN_WAVES 1  // experiment: 512 registers, one wave per SIMD
-#else
 #define CUMF_WAVE_MIN_WAVES 2
-#endif
 // kArithFast epilogue of the Gram pass: the accumulators carry 4096^2 x the Gram; a rating beyond the
 // f16 range (|r| >= 15.99; the table is checked by presplit_f16x2_kernel) shows as a non-finite
 // right-hand side (column f lives in the tiles of the last block column) and is reported through
@@ -1506,9 +1499,6 @@ hipError_t wave_solve_launch<CUMF_WAVE_NB>(const KernelArgs& a, int mode, long n
 
 #endif  // CUMF_WAVE_PART == 0
 
-#ifndef CUMF_WAVE_VARIANT
-#define CUMF_WAVE_VARIANT 0  // A/B switches (tools/wave_variants.sh): 1 = LU without the per-panel scheduling barrier, 2 = no f == 100 instance, 8 = one wave per SIMD
-#endif
 
 #if CUMF_WAVE_PART == 1 && CUMF_WAVE_NB <= 7
 // ---- part 1: the LU form of the wave-per-item kernel
@@ -1534,7 +1524,7 @@ static hipError_t launch_wave_lu(const KernelArgs& a, long n_items, hipStream_t 
 }
 template <>
 hipError_t wave_lu_launch<CUMF_WAVE_NB>(const KernelArgs& a, long n_items, hipStream_t stream) {
-#if CUMF_WAVE_NB == 7 && !(CUMF_WAVE_VARIANT & 2)
+#if CUMF_WAVE_NB == 7
   // the reference's own specialisation: get_hermitian100 for f == 100 (als.cu:788-817)
   if (a.f == 100)
     return a.fast_words ? launch_wave_lu<7, 100, kArithFast>(a, n_items, stream)
@@ -1594,7 +1584,7 @@ hipError_t wave_item_launch<CUMF_WAVE_NB>(const KernelArgs& a, int mode, long n_
   return hipGetLastError();
 #else
   if (mode != kModeMaterialize && mode != kModeLU && mode != kModeCG) return hipErrorInvalidValue;
-#if CUMF_WAVE_NB == 7 && !(CUMF_WAVE_VARIANT & 2)
+#if CUMF_WAVE_NB == 7
   // the reference's own specialisation: get_hermitian100 for f == 100 (als.cu:788-817)
   if (a.f == 100)
     return a.fast_words ? launch_wave_fc<7, 100, kArithFast>(a, mode, n_items, stream)

@@ -349,18 +349,19 @@ def test_dispatched_kernel_name_and_committed_traffic(alslib):
 
 def test_whole_row_kernel_is_bit_identical_to_the_combined_one(alslib):
     """The LU wave kernel has two instances: WHOLE (the plan has no chunked row: no partial-tile exit, 0 spills) and
-    the combined one.  The same rows must come out bit for bit from both: a plan of short rows alone (WHOLE) against
-    the same rows in a plan that also holds one row long enough to be chunked."""
+    the combined one (a plan whose chunked rows hold a quarter or more of its ratings: one launch, the whole rows fill the
+    tail of the chunk items).  The same rows must come out bit for bit from both: a plan of short rows alone (WHOLE)
+    against the same rows in a plan that also holds one row long enough to be chunked and to dominate the plan."""
     _need_gpu()
     from cumf_als_amd import als
 
     f, lam = 100, 0.05
     rng = np.random.RandomState(11)
-    n = 3000
+    n = 9000
     short = list(rng.randint(1, 400, size=40))
     theta = torch.from_numpy(_factors(n, f, 3) - 0.08).cuda()
     out = {}
-    for tag, lens in (("whole", short), ("combined", short + [2500])):
+    for tag, lens in (("whole", short), ("combined", short + [8000])):
         indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
         r2 = np.random.RandomState(5)   # same draws for the common rows (indices and ratings row by row)
         cols, vals = [], []
@@ -848,3 +849,38 @@ def test_doals_rmse_log_fused_vs_kernel(alslib):
         print(f"doALS {solver}: fused log {log_a[:, 0].tolist()} kernel log {log_b[:, 0].tolist()}")
         assert np.abs(log_a - log_b).max() <= 2e-6 * max(1.0, np.abs(log_b).max()), (log_a, log_b)
         assert rm_a == rm_b
+
+
+def test_few_chunked_rows_take_the_split_launch(oracle, alslib):
+    """a plan with a few chunked rows among many whole rows (a Theta side with a handful of very long
+    columns) launches its chunk items apart from the whole rows, which keep the LU instance without the dump exit.
+    Results against the oracle, and bit-identical to the same rows solved from a plan that has no chunked row at all."""
+    _need_gpu()
+    from cumf_als_amd import als
+
+    f, lam = 100, 0.05
+    rng = np.random.RandomState(3)
+    n_rows, n_cols = 600, 5000
+    lens = rng.randint(20, 300, size=n_rows)
+    lens[7], lens[311] = 4500, 3000                      # two long rows: 9 + 6 chunks of 512
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    indices = np.concatenate([rng.choice(n_cols, l, replace=False) for l in lens]).astype(np.int32)
+    data = rng.randint(1, 6, size=indptr[-1]).astype(np.float32)
+    theta = _factors(n_cols, f, 4)
+    x_o = oracle.half_iteration(indptr, indices, data, theta, np.zeros((n_rows, f), np.float32), f, lam, solver="lu")
+    ci, cv, th = torch.from_numpy(indices).cuda(), torch.from_numpy(data).cuda(), torch.from_numpy(theta).cuda()
+    plan = als.Plan(indptr, f, chunk=512)
+    assert plan.n_multi_rows == 2 and plan.n_slots == 15
+    x = torch.zeros((n_rows, f), device="cuda")
+    als.update_fused(plan, ci, cv, th, x, lam, "lu", 6)
+    torch.cuda.synchronize()
+    xh = x.cpu().numpy()
+    assert np.abs(xh - x_o).max() <= 1e-4 * np.abs(x_o).max()
+    assert als.last_kernel_name().endswith("true>")     # the whole rows ran the instance without the dump exit
+    plan_whole = als.Plan(indptr, f, chunk=8192)        # no chunked row: one launch of the same instance
+    x2 = torch.zeros((n_rows, f), device="cuda")
+    als.update_fused(plan_whole, ci, cv, th, x2, lam, "lu", 6)
+    torch.cuda.synchronize()
+    short = np.ones(n_rows, bool)
+    short[[7, 311]] = False
+    np.testing.assert_array_equal(xh[short], x2.cpu().numpy()[short])
