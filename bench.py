@@ -10,10 +10,11 @@ Netflix shape (17770 x 480189, 99 072 112 ratings), f = 100, lambda = 0.048, LU 
 
 Printed JSON (one line, rank 0):
   value       2 * nnz * K / t           ratings/s per half-iteration, whole job
-  roofline    dominant kernel = the per-item Gram(+solve) kernel (its name is read back from the
-              library: the symbol that was dispatched); achieved = algorithmic bytes of a
-              half-iteration (4 f nnz + 8 nnz + 4 (rows+1) + 4 f rows) / its HIP-event
-              duration, averaged over the X-side and Theta-side launches; peak = 8 TB/s HBM.  Emitted
+  roofline    dominant kernel = the per-item Gram(+solve) launch that takes the larger part of the step (the
+              Theta-side instance at the headline shape; its name is read back from the library: the symbol
+              that was dispatched); achieved = algorithmic bytes of that half-iteration (SURVEY.md 8d:
+              4 f nnz + 8 nnz + 4 (rows+1) + 4 f rows) / its HIP-event duration; peak = 8 TB/s HBM.  Both
+              launches are listed (x_side, theta_side) and their mean (step_mean).  Emitted
               for every --f, --solver and for --shape hugewiki (per-GPU slab).  `traffic` is replayed
               from the committed rocprofv3 --pmc passes (profiles/traffic.json), and only when that file
               was collected for the kernel that was dispatched here.
@@ -143,6 +144,33 @@ def parity_at_scale(r, f, lam, solver, cg_iters, oracle_out, dev):
         out[f"{side}_worst_row_len"] = int(lens.max())
         out[f"{side}_max_chunks_per_row"] = int(-(-int(lens.max()) // chunk))
     return out
+
+
+def rmse_log_parity(r, f, lam, solver, cg_iters, iters=3):
+    """`iters` full iterations of the reference's loop (als.cu:727-1022) through doALS with the
+    reference's batch setting X_BATCH = 1, THETA_BATCH = 3 (test_als.sh:16) against oracle_doALS on the same matrix, the
+    same srand(0) start (main.cpp:72-78) and the same truncated test grid: per-iteration train / test RMSE of both and
+    their largest difference (north_star: RMSE to 1e-4).  Outside the timed region; ~10 s of oracle per iteration."""
+    from cumf_als_amd import als
+    from oracle import pyoracle
+
+    d = r.numpy()
+    th0, x0 = pyoracle.init_factors(r.m, r.n, f)
+    t0 = time.time()
+    _, _, rm_h, log_h = als.do_als(d["csr_indptr"], d["csr_indices"], d["csr_data"], d["csc_indices"], d["csc_indptr"],
+                                   d["csc_data"], d["coo_row"], d["test_row"], d["test_col"], d["test_data"], r.m, r.n, f,
+                                   r.nnz, r.nnz_test, lam, iters, 1, 3, torch.cuda.current_device(), thetat_init=th0,
+                                   xt_init=x0, solver=solver, cg_iters=cg_iters, return_log=True)
+    t_hip = time.time() - t0
+    th_o, x_o = th0.copy(), x0.copy()
+    t0 = time.time()
+    rm_o, log_o = pyoracle.do_als(d, th_o, x_o, r.m, r.n, f, lam, iters, x_batch=1, theta_batch=3, solver=solver,
+                                  cg_iters=cg_iters)
+    return {"iterations": iters, "x_batch": 1, "theta_batch": 3, "solver": solver,
+            "hip": [[float(v) for v in row] for row in log_h], "oracle": [[float(v) for v in row] for row in log_o],
+            "max_abs_diff": float(np.abs(np.asarray(log_h, np.float64) - log_o).max()),
+            "final_test_rmse": {"hip": float(rm_h), "oracle": float(rm_o)},
+            "doALS_seconds_incl_upload": round(t_hip, 3), "oracle_seconds": round(time.time() - t0, 1)}
 
 
 def measured_traffic(kernel: str):
@@ -326,6 +354,8 @@ def main() -> int:
     ap.add_argument("--no-gram-leg", action="store_true",
                     help="skip the Gram-pass-alone leg (profiling runs: its solve-less launches would skew per-kernel averages)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rmse-log", action="store_true",
+                    help="skip the 3-iteration doALS-vs-oracle RMSE log of the parity_at_scale leg (~40 s)")
     ap.add_argument("--seed", type=int, default=0)
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -556,14 +586,20 @@ def main() -> int:
         out["dtype"] = ("f32" if not wave else
                         "f32 (opt-in fast mode: pre-split f16x2 operands, 3 products, 22-bit significand, fp32 accumulate)"
                         if mode == "fast" else "f32 (bf16x3-split products on the bf16 matrix pipe, fp32 accumulate)")
+        sx_, st_ = side(xs, bx, "x_side", kernels.get("x")), side(ts, bt, "theta_side", kernels.get("theta"))
+        dom_name, dom = ("theta_side", st_) if ts >= xs else ("x_side", sx_)
         out["roofline"] = {
-            "bound": "hbm", "kernel": kernel,
-            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic.get("bytes_per_launch"), "traffic_source": traffic.get("source") or traffic_note,
-            "alg_bytes_per_launch": avg_bytes, "avg_launch_ms": avg_ms,
+            # the DOMINANT kernel = the launch (symbol) that takes the larger part of the step: its algorithmic bytes over
+            # its own HIP-event duration (not the step mean under the other side's name)
+            "bound": "hbm", "kernel": dom["kernel"], "dominant": dom_name,
+            "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"],
+            "traffic": dom["traffic"], "traffic_source": traffic.get("source") or traffic_note,
+            "alg_bytes_per_launch": dom["alg_bytes"], "avg_launch_ms": dom["ms"],
+            "step_mean": {"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "alg_bytes_per_launch": avg_bytes,
+                          "avg_launch_ms": avg_ms, "traffic": traffic.get("bytes_per_launch")},
             "x_side_ms": xs, "theta_side_ms": ts,
-            "x_side": side(xs, bx, "x_side", kernels.get("x")),
-            "theta_side": side(ts, bt, "theta_side", kernels.get("theta")),
+            "x_side": sx_,
+            "theta_side": st_,
             "reduce_kernel_ms_x_side": sum(red_ms[0::2]) / len(red_ms[0::2]),
             "reduce_kernel_ms_theta_side": sum(red_ms[1::2]) / len(red_ms[1::2]),
             "gram_mode": mode,
@@ -596,6 +632,8 @@ def main() -> int:
             oracle_out, out["cpu_baseline"] = cpu_baseline(d, f, lam, a.solver)
             del eng
             out["parity_at_scale"] = parity_at_scale(r, f, lam, a.solver, a.cg_iters, oracle_out, dev)
+            if a.shape == "netflix" and a.scale == 1.0 and not a.no_rmse_log:
+                out["parity_at_scale"]["rmse_log"] = rmse_log_parity(r, f, lam, a.solver, a.cg_iters)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -12,10 +12,12 @@
 //     processed in that many slices; results do not depend on them.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "als.h"
@@ -116,7 +118,18 @@ extern "C" float cumf_doALS_ex(const int* csrRowIndexHostPtr, const int* csrColI
                                float lambda, int ITERS, int X_BATCH, int THETA_BATCH, int DEVICEID, int solver,
                                int cg_iters, int fused, int exact_test_grid, int surpass_nan, int quiet,
                                float* rmse_log) {
+  // CUMF_ALS_TIMING=1: wall-clock phases of the call on stderr (the reference times its phases under #ifdef DEBUG, als.cu:728-732)
+  const bool phase_timing = env_int("CUMF_ALS_TIMING", 0) != 0;
+  auto t_last = std::chrono::steady_clock::now();
+  auto phase = [&](const char* what) {
+    if (!phase_timing) return;
+    (void)hipDeviceSynchronize();
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "doALS phase %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
   DRV_CHECK(hipSetDevice(DEVICEID));
+  phase("hipSetDevice");
   if (!quiet) printf("*******parameters: m: %d, n:  %d, f: %d, nnz: %ld \n", m, n, f, nnz);
   if (X_BATCH < 1) X_BATCH = 1;
   if (THETA_BATCH < 1) THETA_BATCH = 1;
@@ -130,17 +143,29 @@ extern "C" float cumf_doALS_ex(const int* csrRowIndexHostPtr, const int* csrColI
   DRV_CHECK(cumf_check_gather_table(n, f, solver, !fused));
   DRV_CHECK(cumf_check_gather_table(m, f, solver, !fused));
   if (!quiet) printf("*******start allocating memory on GPU...\n");
-  int* csrColIndex = to_device(csrColIndexHostPtr, (size_t)nnz);
-  float* csrVal = to_device(csrValHostPtr, (size_t)nnz);
-  int* cscRowIndex = to_device(cscRowIndexHostPtr, (size_t)nnz);
-  float* cscVal = to_device(cscValHostPtr, (size_t)nnz);
-  int* cooRowIndex = to_device(cooRowIndexHostPtr, (size_t)nnz);
-  int* cooRowIndex_test = to_device(cooRowIndexTestHostPtr, (size_t)nnz_test);
-  int* cooColIndex_test = to_device(cooColIndexTestHostPtr, (size_t)nnz_test);
-  float* cooVal_test = to_device(cooValHostTestPtr, (size_t)nnz_test);
+  // The uploads (2 GB at the Netflix shape) run on a stream of their own while the host builds the plans below
+  // (sorting ~500 k work items per side); pinned callers (main.cpp:50-69) get true overlap, pageable ones (the TF op) the
+  // staged copy they would get anyway.  Non-blocking: the plans' own small synchronous copies do not wait for it.
+  hipStream_t up = nullptr;
+  DRV_CHECK(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
+  auto to_device_async = [&](auto* host, size_t count) {
+    using T = std::remove_cv_t<std::remove_pointer_t<decltype(host)>>;
+    T* d = nullptr;
+    DRV_CHECK(hipMalloc(reinterpret_cast<void**>(&d), (count ? count : 1) * sizeof(T)));
+    if (host && count) DRV_CHECK(hipMemcpyAsync(d, host, count * sizeof(T), hipMemcpyHostToDevice, up));
+    return d;
+  };
+  int* csrColIndex = to_device_async(csrColIndexHostPtr, (size_t)nnz);
+  float* csrVal = to_device_async(csrValHostPtr, (size_t)nnz);
+  int* cscRowIndex = to_device_async(cscRowIndexHostPtr, (size_t)nnz);
+  float* cscVal = to_device_async(cscValHostPtr, (size_t)nnz);
+  int* cooRowIndex = nullptr;  // only the RMSE kernel reads it (als.cu:972-977): uploaded below if that kernel runs
+  int* cooRowIndex_test = to_device_async(cooRowIndexTestHostPtr, (size_t)nnz_test);
+  int* cooColIndex_test = to_device_async(cooColIndexTestHostPtr, (size_t)nnz_test);
+  float* cooVal_test = to_device_async(cooValHostTestPtr, (size_t)nnz_test);
   if (!quiet) printf("*******start copying memory to GPU...\n");
-  float* thetaT = to_device(thetaTHost, (size_t)n * f);
-  float* XT = to_device(XTHost, (size_t)m * f);
+  float* thetaT = to_device_async(thetaTHost, (size_t)n * f);
+  float* XT = to_device_async(XTHost, (size_t)m * f);
   double* d_sse = to_device<double>(nullptr, 2);
   double* d_bins = to_device<double>(nullptr, CUMF_SSE_BINS);  // fused train SSE of the Theta update
 
@@ -152,10 +177,12 @@ extern "C" float cumf_doALS_ex(const int* csrRowIndexHostPtr, const int* csrColI
     DRV_CHECK(cumf_widen_rowptr(csrRowIndexHostPtr, m, nnz, csr64.data()));
     DRV_CHECK(cumf_widen_rowptr(cscColIndexHostPtr, n, nnz, csc64.data()));
   }
+  phase("hipMalloc + async uploads issued");
   Side sx{csrRowIndexHostPtr, csr64.empty() ? nullptr : csr64.data(), csrColIndex, csrVal, m, X_BATCH, {}, {}, {}};
   Side st{cscColIndexHostPtr, csc64.empty() ? nullptr : csc64.data(), cscRowIndex, cscVal, n, THETA_BATCH, {}, {}, {}};
   make_side(sx, f, n);  // X rows gather from thetaT (n rows)
   make_side(st, f, m);  // Theta rows gather from XT (m rows)
+  phase("plans (host) under the uploads");
 
   // unfused path: Gram batch `tt` (als.cu:782,897) + RHS (ythetaT / yTXT, als.cu:746,864)
   float *tt = nullptr, *rhs = nullptr;
@@ -177,6 +204,10 @@ extern "C" float cumf_doALS_ex(const int* csrRowIndexHostPtr, const int* csrColI
     if (e && strcmp(e, "kernel") == 0) fuse_rmse = false;
     for (cumf_plan_t* p : st.plans) fuse_rmse = fuse_rmse && cumf_fused_sse_available(p, solver);
   }
+  if (!fuse_rmse) cooRowIndex = to_device_async(cooRowIndexHostPtr, (size_t)nnz);
+  DRV_CHECK(hipStreamSynchronize(up));
+  DRV_CHECK(hipStreamDestroy(up));
+  phase("uploads complete");
 
   auto half_iteration = [&](Side& s, const float* gather, float* update, double* sse_bins) {
     for (int b = 0; b < s.nbatch; ++b) {
@@ -257,6 +288,7 @@ extern "C" float cumf_doALS_ex(const int* csrRowIndexHostPtr, const int* csrColI
     }
   }
   DRV_CHECK(hipDeviceSynchronize());
+  phase("iterations");
   if (!range_error) {
     // copy feature vectors back to host (als.cu:1024-1025)
     DRV_CHECK(hipMemcpy(thetaTHost, thetaT, (size_t)n * f * sizeof(float), hipMemcpyDeviceToHost));
@@ -270,6 +302,7 @@ extern "C" float cumf_doALS_ex(const int* csrRowIndexHostPtr, const int* csrColI
   for (void* q : bufs)
     if (q) DRV_CHECK(hipFree(q));
   DRV_CHECK(cumf_release_scratch());  // pooled tile buffers / pre-split tables of the plans above
+  phase("factors back + teardown");
   // the device is NOT reset here (als.cu:1031-1033: "WARN: do not call cudaDeviceReset inside ALS()")
   return range_error ? nanf("") : final_rmse;
 }

@@ -46,6 +46,7 @@ struct cumf_plan {
   int* d_mrow_nslots = nullptr;
   int* d_mrow_rowlen = nullptr;
   float* d_part = nullptr;
+  char* d_block = nullptr;  // the device block all the index arrays below and above point into
   // chunk-only / whole-row-only item lists and the dense-slot tile buffer of the batched
   // "Gram -> tiles -> solver kernel" path (CG on the wave kernels' Gram)
   long n_citems = 0, n_witems = 0;
@@ -83,15 +84,6 @@ int default_chunk(int f, long long nnz) {
   return (c / kStage) * kStage;
 }
 
-template <typename T>
-hipError_t upload(T** dst, const std::vector<T>& src) {
-  *dst = nullptr;
-  if (src.empty()) return hipSuccess;
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(dst), src.size() * sizeof(T));
-  if (e != hipSuccess) return e;
-  return hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice);
-}
-
 }  // namespace
 
 extern "C" int cumf_plan_create(cumf_plan_t** out, const void* rowptr_host, int rowptr_is_64, long rows,
@@ -117,6 +109,11 @@ extern "C" int cumf_plan_create(cumf_plan_t** out, const void* rowptr_host, int 
   std::vector<int> item_row, item_len, item_slot, item_rowlen;
   std::vector<long long> item_begin;
   std::vector<int> mrow_row, mrow_slot0, mrow_nslots, mrow_rowlen;
+  {
+    const size_t guess = (size_t)(row_end - row_begin) + (size_t)((rp(row_end) - rp(row_begin)) / chunk) + 16;
+    item_row.reserve(guess), item_len.reserve(guess), item_slot.reserve(guess), item_rowlen.reserve(guess);
+    item_begin.reserve(guess);
+  }
   long n_slots = 0;
   for (long u = row_begin; u < row_end; ++u) {
     const long long s = rp(u), e = rp(u + 1);
@@ -149,37 +146,18 @@ extern "C" int cumf_plan_create(cumf_plan_t** out, const void* rowptr_host, int 
     }
   }
   // longest-first (stable => deterministic): the hardware dispatches workgroups in
-  // index order, so the short items fill the tail.
-  std::vector<long> order(item_row.size());
-  std::iota(order.begin(), order.end(), 0L);
+  // index order, so the short items fill the tail.  Item lengths are at most `chunk`: a counting sort
+  // (one bucket per length, buckets walked from the longest down) instead of a comparison sort of ~500 k items.
+  const size_t n_it = item_row.size();
+  std::vector<long> order(n_it);
   static const int order_mode = getenv("CUMF_ALS_ORDER") ? atoi(getenv("CUMF_ALS_ORDER")) : 0;
-  if (order_mode == 0)
-    std::stable_sort(order.begin(), order.end(), [&](long a, long b) { return item_len[a] > item_len[b]; });
-  auto permute = [&](auto& v) {
-    auto copy = v;
-    for (size_t i = 0; i < order.size(); ++i) v[i] = copy[order[i]];
-  };
-  permute(item_row);
-  permute(item_begin);
-  permute(item_len);
-  permute(item_slot);
-  permute(item_rowlen);
-
-  std::vector<int> c_row, c_len, c_slot, c_rowlen, w_row, w_len, w_rowlen;
-  std::vector<long long> c_begin, w_begin;
-  for (size_t i = 0; i < item_row.size(); ++i) {  // the sorted order carries over to both sub-lists
-    if (item_slot[i] >= 0) {
-      c_row.push_back(item_row[i]);
-      c_begin.push_back(item_begin[i]);
-      c_len.push_back(item_len[i]);
-      c_slot.push_back(item_slot[i]);
-      c_rowlen.push_back(item_rowlen[i]);
-    } else {
-      w_row.push_back(item_row[i]);
-      w_begin.push_back(item_begin[i]);
-      w_len.push_back(item_len[i]);
-      w_rowlen.push_back(item_rowlen[i]);
-    }
+  if (order_mode == 0) {
+    std::vector<long> start((size_t)chunk + 2, 0);
+    for (size_t i = 0; i < n_it; ++i) ++start[(size_t)(chunk - item_len[i]) + 1];  // bucket 0 = the longest
+    for (size_t k = 1; k < start.size(); ++k) start[k] += start[k - 1];
+    for (size_t i = 0; i < n_it; ++i) order[(size_t)start[(size_t)(chunk - item_len[i])]++] = (long)i;  // stable
+  } else {
+    std::iota(order.begin(), order.end(), 0L);
   }
 
   cumf_plan* p = new cumf_plan();
@@ -190,10 +168,66 @@ extern "C" int cumf_plan_create(cumf_plan_t** out, const void* rowptr_host, int 
   p->nb = nb_for_f(f);
   p->chunk = chunk;
   p->plan_nnz = rp(row_end) - rp(row_begin);
-  p->n_items = (long)item_row.size();
+  p->n_items = (long)n_it;
   p->n_slots = n_slots;
   p->n_mrows = (long)mrow_row.size();
+  for (size_t i = 0; i < n_it; ++i) {
+    if (item_slot[i] >= 0) {
+      ++p->n_citems;
+      p->chunk_nnz += item_len[i];
+    }
+  }
+  p->n_witems = p->n_items - p->n_citems;
   *out = nullptr;
+
+  // ONE device block and ONE upload for the 19 index arrays (a hipMalloc + a synchronous hipMemcpy each cost more than
+  // building the lists: 4 plans x 19 arrays were 40 % of doALS's set-up at the Netflix shape).  256-byte aligned pieces.
+  const size_t ni = n_it, nm = mrow_row.size(), nc = (size_t)p->n_citems, nw = (size_t)p->n_witems;
+  size_t off = 0;
+  auto piece = [&](size_t count, size_t elem) {
+    const size_t at = off;
+    off += (count * elem + 255) & ~(size_t)255;
+    return at;
+  };
+  const size_t o_item_row = piece(ni, 4), o_item_begin = piece(ni, 8), o_item_len = piece(ni, 4), o_item_slot = piece(ni, 4),
+               o_item_rowlen = piece(ni, 4), o_mrow_row = piece(nm, 4), o_mrow_slot0 = piece(nm, 4),
+               o_mrow_nslots = piece(nm, 4), o_mrow_rowlen = piece(nm, 4), o_c_row = piece(nc, 4), o_c_begin = piece(nc, 8),
+               o_c_len = piece(nc, 4), o_c_slot = piece(nc, 4), o_c_rowlen = piece(nc, 4), o_w_row = piece(nw, 4),
+               o_w_begin = piece(nw, 8), o_w_len = piece(nw, 4), o_w_rowlen = piece(nw, 4);
+  std::vector<char> host(off ? off : 256);
+  auto ints = [&](size_t o) { return reinterpret_cast<int*>(host.data() + o); };
+  auto longs = [&](size_t o) { return reinterpret_cast<long long*>(host.data() + o); };
+  {
+    size_t ic = 0, iw = 0;
+    for (size_t k = 0; k < ni; ++k) {  // the sorted order carries over to both sub-lists
+      const size_t i = (size_t)order[k];
+      ints(o_item_row)[k] = item_row[i];
+      longs(o_item_begin)[k] = item_begin[i];
+      ints(o_item_len)[k] = item_len[i];
+      ints(o_item_slot)[k] = item_slot[i];
+      ints(o_item_rowlen)[k] = item_rowlen[i];
+      if (item_slot[i] >= 0) {
+        ints(o_c_row)[ic] = item_row[i];
+        longs(o_c_begin)[ic] = item_begin[i];
+        ints(o_c_len)[ic] = item_len[i];
+        ints(o_c_slot)[ic] = item_slot[i];
+        ints(o_c_rowlen)[ic] = item_rowlen[i];
+        ++ic;
+      } else {
+        ints(o_w_row)[iw] = item_row[i];
+        longs(o_w_begin)[iw] = item_begin[i];
+        ints(o_w_len)[iw] = item_len[i];
+        ints(o_w_rowlen)[iw] = item_rowlen[i];
+        ++iw;
+      }
+    }
+    for (size_t k = 0; k < nm; ++k) {
+      ints(o_mrow_row)[k] = mrow_row[k];
+      ints(o_mrow_slot0)[k] = mrow_slot0[k];
+      ints(o_mrow_nslots)[k] = mrow_nslots[k];
+      ints(o_mrow_rowlen)[k] = mrow_rowlen[k];
+    }
+  }
 #define PLAN_CHECK(call)                                                                                    \
   do {                                                                                                      \
     hipError_t err__ = (call);                                                                              \
@@ -204,27 +238,18 @@ extern "C" int cumf_plan_create(cumf_plan_t** out, const void* rowptr_host, int 
       return (int)err__;                                                                                    \
     }                                                                                                       \
   } while (0)
-  PLAN_CHECK(upload(&p->d_item_row, item_row));
-  PLAN_CHECK(upload(&p->d_item_begin, item_begin));
-  PLAN_CHECK(upload(&p->d_item_len, item_len));
-  PLAN_CHECK(upload(&p->d_item_slot, item_slot));
-  PLAN_CHECK(upload(&p->d_item_rowlen, item_rowlen));
-  PLAN_CHECK(upload(&p->d_mrow_row, mrow_row));
-  PLAN_CHECK(upload(&p->d_mrow_slot0, mrow_slot0));
-  PLAN_CHECK(upload(&p->d_mrow_nslots, mrow_nslots));
-  PLAN_CHECK(upload(&p->d_mrow_rowlen, mrow_rowlen));
-  p->n_citems = (long)c_row.size();
-  for (int len : c_len) p->chunk_nnz += len;
-  p->n_witems = (long)w_row.size();
-  PLAN_CHECK(upload(&p->d_c_row, c_row));
-  PLAN_CHECK(upload(&p->d_c_begin, c_begin));
-  PLAN_CHECK(upload(&p->d_c_len, c_len));
-  PLAN_CHECK(upload(&p->d_c_slot, c_slot));
-  PLAN_CHECK(upload(&p->d_c_rowlen, c_rowlen));
-  PLAN_CHECK(upload(&p->d_w_row, w_row));
-  PLAN_CHECK(upload(&p->d_w_begin, w_begin));
-  PLAN_CHECK(upload(&p->d_w_len, w_len));
-  PLAN_CHECK(upload(&p->d_w_rowlen, w_rowlen));
+  PLAN_CHECK(hipMalloc(reinterpret_cast<void**>(&p->d_block), host.size()));
+  PLAN_CHECK(hipMemcpy(p->d_block, host.data(), host.size(), hipMemcpyHostToDevice));
+  auto dints = [&](size_t o, size_t count) { return count ? reinterpret_cast<int*>(p->d_block + o) : nullptr; };
+  auto dlongs = [&](size_t o, size_t count) { return count ? reinterpret_cast<long long*>(p->d_block + o) : nullptr; };
+  p->d_item_row = dints(o_item_row, ni), p->d_item_begin = dlongs(o_item_begin, ni), p->d_item_len = dints(o_item_len, ni);
+  p->d_item_slot = dints(o_item_slot, ni), p->d_item_rowlen = dints(o_item_rowlen, ni);
+  p->d_mrow_row = dints(o_mrow_row, nm), p->d_mrow_slot0 = dints(o_mrow_slot0, nm);
+  p->d_mrow_nslots = dints(o_mrow_nslots, nm), p->d_mrow_rowlen = dints(o_mrow_rowlen, nm);
+  p->d_c_row = dints(o_c_row, nc), p->d_c_begin = dlongs(o_c_begin, nc), p->d_c_len = dints(o_c_len, nc);
+  p->d_c_slot = dints(o_c_slot, nc), p->d_c_rowlen = dints(o_c_rowlen, nc);
+  p->d_w_row = dints(o_w_row, nw), p->d_w_begin = dlongs(o_w_begin, nw), p->d_w_len = dints(o_w_len, nw);
+  p->d_w_rowlen = dints(o_w_rowlen, nw);
   if (n_slots > 0) {
     const size_t tiles = (size_t)p->nb * (p->nb + 1) / 2;
     PLAN_CHECK(hipMalloc(reinterpret_cast<void**>(&p->d_part), (size_t)n_slots * tiles * 256 * sizeof(float)));
@@ -236,12 +261,8 @@ extern "C" int cumf_plan_create(cumf_plan_t** out, const void* rowptr_host, int 
 
 extern "C" int cumf_plan_destroy(cumf_plan_t* p) {
   if (!p) return 0;
-  void* ptrs[] = {p->d_item_row,  p->d_item_begin,  p->d_item_len,    p->d_item_slot,   p->d_item_rowlen,
-                  p->d_mrow_row,  p->d_mrow_slot0,  p->d_mrow_nslots, p->d_mrow_rowlen, p->d_part,
-                  p->d_c_row,     p->d_c_begin,     p->d_c_len,       p->d_c_slot,      p->d_c_rowlen,
-                  p->d_w_row,     p->d_w_begin,     p->d_w_len,       p->d_w_rowlen};
-  for (void* q : ptrs)
-    if (q) (void)hipFree(q);
+  if (p->d_block) (void)hipFree(p->d_block);  // every index array lives in this one block
+  if (p->d_part) (void)hipFree(p->d_part);
   delete p;
   return 0;
 }
