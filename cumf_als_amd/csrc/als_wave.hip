@@ -637,7 +637,7 @@ __host__ __device__ constexpr int lu_prep_steps() { return 2 * (NB - Ip) + 8; }
 //                            no data movement.  Both operands are the same w: the accumulators hold -A (negated once, with
 //                            the diagonal term) so that the update is the positive product w_k[i] w_k[j].
 // Cholesky-like scaling, LU-like pivots: u_kk > 0 for the positive definite systems of ALS; an all-zero system gives NaN as
-// the reference's unpivoted LU does.  Parity is by tolerance (the order of operations differs from the oracle's).
+// the reference's unpivoted LU does.  Parity is by tolerance (the order of operations is not that of the right-looking loop the test restatement runs).
 // What it bought (profiles/r04/lu_parts.txt, lu_three_way_ab.txt): the solve alone 4.55 -> 4.25 ms per Netflix Theta pass
 // (480 189 systems), Theta side at f = 64 6.30 -> 5.87 ms, at f = 100 10.9 -> 10.8 ms (inside the box-to-box noise): a fused
 // half-iteration costs the SUM of its Gram pass and its solve -- both phases are bound by VALU-type issue slots (an MFMA is
@@ -955,12 +955,14 @@ __device__ __forceinline__ float row16_sum4_transposed(float r0, float r1, float
   w += dpp_term<0x128, 0xf>(w);                // row_ror:8
   return w;
 }
-// Two FMAs on a register pair.  NOT v_pk_fma_f32: the packed form (98 of them per CG iteration instead of 196
-// scalar FMAs) returned WRONG mat-vecs on 1-4 % of the long rows of the Netflix X side, a different set of rows in
-// every run, while the partner wave of the SIMD was in its MFMA phase (profiles/r03/pk_fma_bisect.txt: the same
-// source with scalar FMAs is clean, with either row reduction).  No software hazard explains it (even-aligned pairs,
-// counted lgkmcnt, the DPP wait states are there), so packed fp32 arithmetic stays out of kernels that share a SIMD
-// with MFMA work (-fno-slp-vectorize keeps the compiler from forming it on its own).
+// Two FMAs on a register pair, as two scalar v_fma_f32.  NOT v_pk_fma_f32: with the packed form (98 per CG iteration instead
+// of 196 scalar FMAs) 1-4 % of the long rows of the Netflix X side came back with wrong mat-vecs, a different set of rows in
+// every run, while the partner wave of the SIMD was in its MFMA phase (profiles/r03/pk_fma_bisect.txt: four builds of this
+// file; the same source with scalar FMAs is clean with either row reduction).  UNEXPLAINED -- no standalone reproducer
+// exists, and a missed wait state in the neighbouring inline DPP / ds_bpermute sequences that the packed form's scheduling
+// merely exposes cannot be excluded -- and therefore AVOIDED: -fno-slp-vectorize keeps the compiler from forming packed
+// fp32 math on its own, tests/test_capi_symbols.py::test_no_packed_fp32_math_in_wave_kernels disassembles the built
+// objects and fails if any appears, and test_sampled_rows_match_oracle_at_full_size checks 1 000 long rows per run.
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) {
   return f32x2{fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])};
 }
