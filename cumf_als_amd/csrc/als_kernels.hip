@@ -116,7 +116,7 @@ struct Stager {
   int rsub, col0;
 
   // The steady-state stage loop must stay ONE basic block with as few VALU instructions as
-  // possible: measured with tools/mfma_ladder.hip, every VALU instruction issued next to the
+  // possible: measured with tools/probes/mfma_ladder.hip, every VALU instruction issued next to the
   // MFMAs costs matrix-pipe time, and a load under a branch degrades every s_waitcnt to
   // vmcnt(0).  So: full stages take a select-free path (feature lanes store what they loaded,
   // the zero padding of the stage rows is written once per item, the rating goes through its

@@ -78,7 +78,7 @@ __device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast
 // x - (low / high bf16 of p), exact whenever the difference is representable (it is for the residuals of
 // the split): one v_dot2c_f32_bf16 (x += p.lo * s.lo + p.hi * s.hi with s = (-1, 0) / (0, -1)) instead of
 // unpack + subtract.  The selector pairs sit in SGPRs: as immediates the compiler emits the inline
-// constant -1.0, which the instruction does not read as the bf16 pair (tools/dot2_probe.hip).
+// constant -1.0, which the instruction does not read as the bf16 pair (tools/probes/dot2_probe.hip).
 __device__ __forceinline__ float sub_bf16_lo(float x, unsigned p) {
   unsigned sel;
   asm("s_mov_b32 %0, 0xbf80" : "=s"(sel));
@@ -621,7 +621,7 @@ __host__ __device__ constexpr int lu_prep_steps() { return 2 * (NB - Ip) + 8; }
 
 // ----------------------------------------------------------------------------------
 // The elimination BLOCKED by block rows (round 4: lu_wave_blocked, the LU the wave kernels run).  Measured on this part
-// (tools/issue_probe3.hip, profiles/r04/issue_probe3.txt): v_mfma_f32_16x16x4_f32 takes 36 cycles and does NOT run beside
+// (tools/probes/issue_probe3.hip, profiles/r04/issue_probe3.txt): v_mfma_f32_16x16x4_f32 takes 36 cycles and does NOT run beside
 // VALU work -- neither of its own wave nor of the partner wave (8 MFMAs + 48 v_fma: 611 cycles against 293 + 379) -- so the
 // 333 rank-4 updates of the panel-serial form (12 k cycles) simply add to its ~2 200 VALU instructions (10 k): 21.5 k cycles
 // per system, which is what the Theta side showed, and why interleaving them inside the wave bought 1 %.  The bf16 MFMA is

@@ -1,5 +1,5 @@
 // Is v_dot2c_f32_bf16 usable for the exact residual x - bf16(x) of the three-plane split?
-// build: hipcc --offload-arch=gfx950 -O3 -w tools/dot2_probe.hip -o tools/_bin/dot2_probe
+// build: hipcc --offload-arch=gfx950 -O3 -w tools/probes/dot2_probe.hip -o tools/_bin/dot2_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -1,5 +1,5 @@
 // Does a SIMD overlap one wave's VALU with another wave's (or its own) MFMAs?
-// build: hipcc --offload-arch=gfx950 -O3 tools/issue_probe.hip -o gpurun_out/issue_probe
+// build: hipcc --offload-arch=gfx950 -O3 tools/probes/issue_probe.hip -o gpurun_out/issue_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -1,6 +1,6 @@
 // Which VALU instructions hide behind v_mfma_f32_16x16x32_bf16 on gfx950, and which add to it?
 // Per loop iteration: 8 MFMAs (independent accumulators), each followed by NV / 8 instructions of one kind.
-// build: hipcc --offload-arch=gfx950 -O3 tools/issue_probe2.hip -o gpurun_out/issue_probe2
+// build: hipcc --offload-arch=gfx950 -O3 tools/probes/issue_probe2.hip -o gpurun_out/issue_probe2
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x4 __attribute__((ext_vector_type(4)));

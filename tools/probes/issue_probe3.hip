@@ -3,7 +3,7 @@
 //   same  : every wave runs MFMAs with NV filler instructions interleaved (NV / 8 behind each MFMA)
 //   split : waves 0..3 of a 512-thread block run only the MFMAs, waves 4..7 only the fillers (wave w sits on SIMD w % 4:
 //           one MFMA wave + one filler wave per SIMD)
-// build: hipcc --offload-arch=gfx950 -O3 tools/issue_probe3.hip -o tools/_bin/issue_probe3
+// build: hipcc --offload-arch=gfx950 -O3 tools/probes/issue_probe3.hip -o tools/_bin/issue_probe3
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -1,6 +1,6 @@
 // Probe of global_load_lds_dword semantics on gfx950 (tools only): where does lane l's dword land
 // for a given LDS base pointer and instruction offset?  Build + run on the GPU box:
-//   hipcc --offload-arch=gfx950 -O2 tools/lds_dma_probe.hip -o /tmp/lds_dma_probe && /tmp/lds_dma_probe
+//   hipcc --offload-arch=gfx950 -O2 tools/probes/lds_dma_probe.hip -o /tmp/lds_dma_probe && /tmp/lds_dma_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
