@@ -843,7 +843,8 @@ __device__ __forceinline__ float lu_wave_blocked(f32x4 (&acc)[NB * (NB + 1) / 2]
       constexpr int p0 = 16 * Ip + 4 * q;
       constexpr bool last_row = Ip == NB - 1;
       constexpr bool exists_static = !last_row || (FC != 0 && p0 < FC);
-      constexpr bool dyn = last_row && FC == 0;
+      constexpr bool dyn = last_row && FC == 0;            // the panel exists only if p0 < f (run time)
+      constexpr bool dynp = (last_row && (FC & 3) != 0) || dyn;  // ... and may be short (a compile-time f that is no multiple of 4 too)
       auto panel = [&]() {
         float wm = 0.f;
 #if CUMF_ABLATE
@@ -862,7 +863,7 @@ __device__ __forceinline__ float lu_wave_blocked(f32x4 (&acc)[NB * (NB + 1) / 2]
             constexpr int n = n0 + decltype(nc)::value;
             lu_trailing_mfma<NB, lu_trailing_tile<NB, Ip + 1>(n % NTl), n / NTl>(acc, h, m, l);
           });
-          lu_prep_step_s<NB, Ip, q, dyn, i>(acc, s, w[q], wm, rdiag, f, ln);
+          lu_prep_step_s<NB, Ip, q, dynp, i>(acc, s, w[q], wm, rdiag, f, ln);
           if constexpr (TP > 0) __builtin_amdgcn_sched_barrier(0);
         });
         // the block row's own tiles: what its next panel reads (and the rows the back substitution reads later)

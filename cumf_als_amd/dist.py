@@ -118,6 +118,9 @@ class HipOps:
     def check(self) -> None:
         self.als.check_gram_fast()
 
+    def release_scratch(self) -> None:
+        self.als.release_scratch()
+
     def get_hermitian(self, plan, colidx, val, gather, lam, tt, rhs):
         self.als.get_hermitian(plan, colidx, val, gather, lam, tt, rhs)
 
@@ -613,3 +616,10 @@ class DistALS:
         check = getattr(self.ops, "check", None)  # gram mode "fast": range report of the HIP ops
         if check is not None:
             check()
+
+    def close(self) -> None:
+        """Hand the library's pooled scratch of this device back (tile buffers of the f >= 144 LU path, pre-split tables of
+        gram mode "fast": up to 48 GiB outside torch's caching allocator)."""
+        release = getattr(self.ops, "release_scratch", None)
+        if release is not None:
+            release()

@@ -108,8 +108,9 @@ def main(argv=None) -> int:
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     try:
-        run(a.split_dir, a.n, a.f, a.lam, a.iters, a.solver, a.cg_iters, a.theta_batch, solver_x=a.solver_x,
-            solver_theta=a.solver_theta, cg_iters_x=a.cg_iters_x, cg_iters_theta=a.cg_iters_theta)
+        eng, _ = run(a.split_dir, a.n, a.f, a.lam, a.iters, a.solver, a.cg_iters, a.theta_batch, solver_x=a.solver_x,
+                     solver_theta=a.solver_theta, cg_iters_x=a.cg_iters_x, cg_iters_theta=a.cg_iters_theta)
+        eng.close()  # the library's pooled scratch of this device
     finally:
         if world > 1:
             dist.destroy_process_group()
