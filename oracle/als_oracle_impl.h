@@ -195,16 +195,24 @@ double FN(oracle_sse)(const float *val, const int *row, const int *col,
   enum { ERROR_SIZE = 1000 };
   REAL bins[ERROR_SIZE];
   for (int i = 0; i < ERROR_SIZE; i++) bins[i] = 0;
-  for (long i = 0; i < count; i++) {
-    REAL e = (REAL)val[i];
-    const REAL *th = thetaT + (size_t)col[i] * f;
-    const REAL *xr = XT + (size_t)row[i] * f;
-    for (int k = 0; k < f; k++) {
-      REAL a = th[k], bb = xr[k];
-      if (surpass_nan && (a != a || bb != bb)) break;
-      e = FN(fma_)(-a, bb, e);
+  /* Bin b receives the ratings i = b, b + 1000, ... in increasing i (the order a sequential walk over i gives it):
+   * the bins are independent, so walking them in parallel changes no bit of any of them. */
+  int b;
+#pragma omp parallel for schedule(dynamic, 8)
+  for (b = 0; b < ERROR_SIZE; b++) {
+    REAL acc = 0;
+    for (long i = b; i < count; i += ERROR_SIZE) {
+      REAL e = (REAL)val[i];
+      const REAL *th = thetaT + (size_t)col[i] * f;
+      const REAL *xr = XT + (size_t)row[i] * f;
+      for (int k = 0; k < f; k++) {
+        REAL a = th[k], bb = xr[k];
+        if (surpass_nan && (a != a || bb != bb)) break;
+        e = FN(fma_)(-a, bb, e);
+      }
+      acc += e * e;
     }
-    bins[i % ERROR_SIZE] += e * e;
+    bins[b] = acc;
   }
   REAL sum = 0;
   for (int i = 0; i < ERROR_SIZE; i++) sum += (bins[i] < 0 ? -bins[i] : bins[i]); /* Sasum */
