@@ -956,14 +956,14 @@ __device__ __forceinline__ float row16_sum4_transposed(float r0, float r1, float
   w += dpp_term<0x128, 0xf>(w);                // row_ror:8
   return w;
 }
-// Two FMAs on a register pair, as two scalar v_fma_f32.  NOT v_pk_fma_f32: with the packed form (98 per CG iteration instead
-// of 196 scalar FMAs) 1-4 % of the long rows of the Netflix X side came back with wrong mat-vecs, a different set of rows in
-// every run, while the partner wave of the SIMD was in its MFMA phase (profiles/r03/pk_fma_bisect.txt: four builds of this
-// file; the same source with scalar FMAs is clean with either row reduction).  UNEXPLAINED -- no standalone reproducer
-// exists, and a missed wait state in the neighbouring inline DPP / ds_bpermute sequences that the packed form's scheduling
-// merely exposes cannot be excluded -- and therefore AVOIDED: -fno-slp-vectorize keeps the compiler from forming packed
-// fp32 math on its own, tests/test_capi_symbols.py::test_no_packed_fp32_math_in_wave_kernels disassembles the built
-// objects and fails if any appears, and test_sampled_rows_match_oracle_at_full_size checks 1 000 long rows per run.
+// Two FMAs on a register pair, as two scalar v_fma_f32.  Round 3 saw wrong CG mat-vecs (1-4 % of the long Netflix X rows, a
+// different set every run) in a build whose compiler had formed v_pk_fma_f32 here (profiles/r03/pk_fma_bisect.txt) and
+// kept packed fp32 math out ever since (-fno-slp-vectorize; tests/test_capi_symbols.py disassembles the objects).  Round 4
+// looked again: a standalone probe (tools/probes/pk_fma_probe.hip: 3e12 packed FMAs feeding DPP reductions and ds_bpermute
+// beside bf16 and fp32 MFMA waves, against scalar FMAs: 0 mismatches) and this very CG with fma2 spelled as ONE inline-asm
+// v_pk_fma_f32 (full-size oracle rows green three times, RMSE identical to 1e-16, profiles/r04/pk_fma_cg_ab.txt) are
+// clean -- the instruction is not at fault, that build's generated code was -- and the packed CG is 5 % SLOWER (the packed
+// FMA issues at half rate and needs aligned register pairs): the scalar form stays, for speed.
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) {
   return f32x2{fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])};
 }
