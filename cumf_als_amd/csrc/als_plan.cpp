@@ -590,12 +590,19 @@ extern "C" int cumf_als_update_fused(const cumf_plan_t* p, const int* colidx, co
   return update_fused_impl(p, colidx, val, gather, update, f, lambda, solver, cg_iters, nullptr, stream);
 }
 
-// Can the half-iteration of this plan also deliver the train SSE of its rows (cumf_als_update_fused_sse)?  Yes when
-// every row is solved inside the wave-per-item kernel: 16 <= f <= 111, gram mode not "exact", no chunked row in the plan.
+// Can the half-iteration of this plan also deliver the train SSE of its rows (cumf_als_update_fused_sse)?  LU: when every
+// row is solved inside the wave-per-item kernel (16 <= f <= 111, no chunked row).  CG: wherever the wave kernels' CG runs
+// (16 <= f <= 207, see below).  Never in gram mode "exact" (workgroup kernels).
 extern "C" int cumf_fused_sse_available(const cumf_plan_t* p, int solver) {
   if (!p) return 0;
   const int mode = solver == CUMF_SOLVER_LU ? kModeLU : kModeCG;
-  return wave_path_available(p->f, mode) && p->n_mrows == 0;
+  if (mode == kModeLU) return wave_path_available(p->f, mode) && p->n_mrows == 0;  // lu_wave_blocked, whole rows
+  // CG: every solve of the wave kernels runs cg_wave_core -- one wave per row (f <= 111, chunked rows included:
+  // als_wave_cg_kernel), the two-wave kernel (f >= 112) for whole rows, als_wave_cg_kernel with four waves for chunked rows
+  // above f = 128.  Chunked rows at f = 112 .. 128 go to the LDS-resident four-wave CG of als_reduce_kernel: not covered.
+  if (wave_path_available(p->f, mode)) return 1;
+  if (wave_batched_path(p->f, mode)) return p->n_mrows == 0 || p->f > kVecLd;
+  return 0;
 }
 
 // cumf_als_update_fused + the train SSE of the updated rows for free (als.cu:979-991 folded into the update, see

@@ -1153,12 +1153,16 @@ __device__ __forceinline__ void cg_wave_core(f32x4 (&T)[(NB * (NB + 1) / 2 + NW 
       if (live[J]) xg[16 * J + c] = x[J];
     });
   }
-  if constexpr (NW == 1) {
-    if (a.sse_bins != nullptr) {  // fused train SSE: S - x.b - x.r - reg |x|^2 (see wave_tile_ff)
-      constexpr int NT1 = NB * (NB + 1) / 2;
-      const float S = wave_tile_ff<NB>(T[NT1 - 1], f) - reg;  // the diagonal carries reg in slot f too
-      const float xb = dot(x, b), xr = dot(x, r), xx = dot(x, x);
-      wave_sse_add(a.sse_bins, (double)S - (double)xb - (double)xr - (double)reg * (double)xx, rowlen, lane);
+  {
+    // fused train SSE: S - x.b - x.r - reg |x|^2 (see wave_tile_ff).  Every wave holds all the vectors (identical bits);
+    // the one that owns the last diagonal tile -- entry (f, f) = sum r^2 -- reports.
+    constexpr int NT1 = NB * (NB + 1) / 2;
+    if constexpr ((NT1 - 1) % NW == W) {
+      if (a.sse_bins != nullptr) {
+        const float S = wave_tile_ff<NB>(T[(NT1 - 1) / NW], f) - reg;  // the diagonal carries reg in slot f too
+        const float xb = dot(x, b), xr = dot(x, r), xx = dot(x, x);
+        wave_sse_add(a.sse_bins, (double)S - (double)xb - (double)xr - (double)reg * (double)xx, rowlen, lane);
+      }
     }
   }
 }
