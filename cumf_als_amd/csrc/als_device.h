@@ -164,6 +164,17 @@ __device__ __forceinline__ void back_substitute_zeroed(const float* __restrict__
   });
 }
 
+// Entry (f, f) of the augmented system -- the rating rides in slot f of the gathered rows, so the Gram pass accumulates
+// sum r^2 there (the fused train SSE starts from it, als_wave.hip) -- out of the last diagonal tile, wave-uniform.
+template <int NB>
+__device__ __forceinline__ float wave_tile_ff(const f32x4& last_diag, int f) {
+  const int cf = f - 16 * (NB - 1);  // slot f inside the last block: lane (cf >> 2, cf), register cf & 3
+  float v = last_diag[0];
+  v = (cf & 3) == 1 ? last_diag[1] : v;
+  v = (cf & 3) == 2 ? last_diag[2] : v;
+  v = (cf & 3) == 3 ? last_diag[3] : v;
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16 * (cf >> 2) + cf));
+}
 }  // namespace cumf
 
 #endif  // CUMF_ALS_DEVICE_H_

@@ -704,7 +704,7 @@ template <int NB, int MODE, int W>
 __device__ __forceinline__ void finish_row(f32x4 (&acc)[Geo<NB>::TPW], float* smem, const KernelArgs& a, int row,
                                            int rowlen, int tid) {
   if constexpr (MODE == kModeLU && lu_on_accumulators(NB)) {
-    lu_solve_mfma<NB, W>(acc, smem, a.f, (float)rowlen * a.lambda, a.update + (size_t)row * a.f, tid);
+    lu_solve_mfma<NB, W>(acc, smem, a.f, (float)rowlen * a.lambda, a.update + (size_t)row * a.f, tid, a.sse_bins, rowlen);
   } else {
     dump_row<NB, MODE, W>(acc, smem, a, row, rowlen, tid & 63);
   }

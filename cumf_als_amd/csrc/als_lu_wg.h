@@ -95,7 +95,7 @@ struct LuLds {
 };
 template <int NB>
 __host__ __device__ constexpr size_t lu_wg_lds_floats(int f) {
-  return (size_t)LuLds<NB>::kX + LuLds<NB>::kT + ((f + 3) & ~3) + 48;
+  return (size_t)LuLds<NB>::kX + LuLds<NB>::kT + ((f + 3) & ~3) + 64;  // + 2 x 16 multipliers, 16 zeros, 16 spare (train SSE)
 }
 
 // Back substitution U x = y by the workgroup, straight from the accumulator tiles of the four roles
@@ -104,7 +104,7 @@ __host__ __device__ constexpr size_t lu_wg_lds_floats(int f) {
 // barrier, wave 0 (lane i = rows i, i + 64, ...) reads the 16 entries of its rows and runs the 16 steps,
 // barrier.  2 (NB) barriers instead of a 95 KB row store.
 template <int NB, int W, int NQ, int NW>
-__device__ __forceinline__ void back_substitute_tiles_wg(const LuAcc<NB, NW>& acc, float* __restrict__ T,
+__device__ __forceinline__ float back_substitute_tiles_wg(const LuAcc<NB, NW>& acc, float* __restrict__ T,
                                                          const float* __restrict__ rdiag,
                                                          const float* __restrict__ zpad, int f,
                                                          float* __restrict__ x_global, int lane) {
@@ -175,17 +175,24 @@ __device__ __forceinline__ void back_substitute_tiles_wg(const LuAcc<NB, NW>& ac
     }
     if constexpr (kb > 0) __syncthreads();  // the window is rewritten for the next block column
   });
+  float ssq = 0.f;  // wave 0: this lane's share of ||x||^2 (rows past f hold zeros)
   if constexpr (W == 0) {
     static_for<NQ>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
       if (lane + 64 * q < f) x_global[lane + 64 * q] = z[q];
+      ssq = fmaf(z[q], z[q], ssq);
     });
   }
+  return ssq;
 }
 
+// sse_bins != nullptr: the train SSE of the row for free, as in lu_wave_blocked (als_wave.hip, wave_tile_ff): entry (f, f)
+// of the eliminated system is the Schur complement sum r^2 + reg - b^T A^-1 b, so SSE = (f, f) - reg (1 + |x|^2); the role
+// that owns the last diagonal tile hands (f, f) to wave 0 through LDS.
 template <int NB, int W, int NW = 4>
 __device__ __forceinline__ void lu_solve_mfma(LuAcc<NB, NW>& acc, float* __restrict__ lds, int f, float reg,
-                                              float* __restrict__ x_global, int tid) {
+                                              float* __restrict__ x_global, int tid, double* sse_bins = nullptr,
+                                              int rowlen = 0) {
   constexpr int NT = LuGeo<NB, NW>::NT, TPW = LuGeo<NB, NW>::TPW;
   const int lane = tid & 63, c = lane & 15, kk = lane >> 4;
   float* X = lds;                                 // published raw panel rows, [parity][r][16 NB]
@@ -324,8 +331,22 @@ __device__ __forceinline__ void lu_solve_mfma(LuAcc<NB, NW>& acc, float* __restr
     }
   });
   // the eliminated rows stay in the accumulators (the masked update leaves rows at and above a pivot alone)
+  float* ff_slot = zpad + 16;
+  if constexpr ((NT - 1) % NW == W) {
+    if (sse_bins != nullptr) {
+      const float ff = wave_tile_ff<NB>(acc[(NT - 1) / NW], f);
+      if (lane == 0) ff_slot[0] = ff;
+    }
+  }
   __syncthreads();  // rdiag is complete
-  back_substitute_tiles_wg<NB, W, (16 * NB + 63) / 64, NW>(acc, Twin, rdiag, zpad, f, x_global, lane);
+  const float ssq = back_substitute_tiles_wg<NB, W, (16 * NB + 63) / 64, NW>(acc, Twin, rdiag, zpad, f, x_global, lane);
+  if constexpr (W == 0) {
+    if (sse_bins != nullptr) {
+      const float tt = wave_sum_uniform(ssq);
+      if (lane == 0 && rowlen > 0)
+        atomicAdd(sse_bins + (blockIdx.x & (kSseBins - 1)), (double)ff_slot[0] - (double)reg * (1.0 + (double)tt));
+    }
+  }
 }
 
 }  // namespace cumf

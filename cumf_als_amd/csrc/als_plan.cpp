@@ -596,7 +596,13 @@ extern "C" int cumf_als_update_fused(const cumf_plan_t* p, const int* colidx, co
 extern "C" int cumf_fused_sse_available(const cumf_plan_t* p, int solver) {
   if (!p) return 0;
   const int mode = solver == CUMF_SOLVER_LU ? kModeLU : kModeCG;
-  if (mode == kModeLU) return wave_path_available(p->f, mode) && p->n_mrows == 0;  // lu_wave_blocked, whole rows
+  if (mode == kModeLU) {
+    // whole rows: lu_wave_blocked (f <= 111) / lu_solve_mfma with two wave roles in place (f = 112 .. 143) or with four
+    // from the tile buffer (f >= 144); chunked rows: als_reduce_kernel, whose LU is lu_solve_mfma from NB = 7 on (below
+    // that the thread-grid LU of the packed row store: not covered)
+    if (wave_path_available(p->f, mode)) return p->n_mrows == 0 || p->nb >= 7;
+    return wave_batched_path(p->f, mode);
+  }
   // CG: every solve of the wave kernels runs cg_wave_core -- one wave per row (f <= 111, chunked rows included:
   // als_wave_cg_kernel), the two-wave kernel (f >= 112) for whole rows, als_wave_cg_kernel with four waves for chunked rows
   // above f = 128.  Chunked rows at f = 112 .. 128 go to the LDS-resident four-wave CG of als_reduce_kernel: not covered.

@@ -592,15 +592,6 @@ __device__ __forceinline__ float back_substitute_tiles(const f32x4 (&acc)[NB * (
 // No rating and no factor row is read again.  One fp64 atomic per row into kSseBins bins (the reference's own
 // error bins, als.cu:216, hold fp32 partial sums); rows without ratings contribute nothing.
 // ----------------------------------------------------------------------------------
-template <int NB>
-__device__ __forceinline__ float wave_tile_ff(const f32x4& last_diag, int f) {
-  const int cf = f - 16 * (NB - 1);  // slot f inside the last block: lane (cf >> 2, cf), register cf & 3
-  float v = last_diag[0];
-  v = (cf & 3) == 1 ? last_diag[1] : v;
-  v = (cf & 3) == 2 ? last_diag[2] : v;
-  v = (cf & 3) == 3 ? last_diag[3] : v;
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16 * (cf >> 2) + cf));
-}
 __device__ __forceinline__ void wave_sse_add(double* bins, double sse, int rowlen, int lane) {
   if (lane == 0 && rowlen > 0) atomicAdd(bins + (blockIdx.x & (kSseBins - 1)), sse);
 }
@@ -1444,7 +1435,7 @@ __device__ __forceinline__ void multi_body(float* smem, const KernelArgs& a, lon
       cg_wave_core<NB, NW, W>(acc, smem, a, f, row, rowlen, lane);
     } else {
       __syncthreads();  // the partner is done with the stage buffers: the LU's exchange buffers alias them
-      lu_solve_mfma<NB, W, NW>(acc, smem, f, (float)rowlen * a.lambda, a.update + (size_t)row * f, lane);
+      lu_solve_mfma<NB, W, NW>(acc, smem, f, (float)rowlen * a.lambda, a.update + (size_t)row * f, lane, a.sse_bins, rowlen);
     }
     return;
   }

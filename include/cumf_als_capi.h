@@ -95,9 +95,9 @@ int cumf_als_update_fused(const cumf_plan_t* plan, const int* colidx, const floa
  * sum r^2 + lambda n - b^T A^-1 b, CG supplies x.b, x.r, |x|^2: sum_u (r - x_u . t)^2 = sum r^2 - 2 t.b + t^T G t
  * follows without reading a rating or a factor row again.  sse_bins: CUMF_SSE_BINS doubles in DEVICE
  * memory, zeroed by the caller, ADDED to (fp64 atomics); the SSE is their sum.  Only when
- * cumf_fused_sse_available(plan, solver) -- LU: every row solved inside the wave-per-item kernel (16 <= f <= 111, no
- * chunked row); CG: wherever the wave kernels' CG runs (16 <= f <= 207; not for chunked rows at f = 112 .. 128); never
- * in gram mode "exact" -- otherwise an error, and cumf_sse is the way.
+ * cumf_fused_sse_available(plan, solver) -- wherever the wave kernels' solvers run: 16 <= f <= 207, gram mode not
+ * "exact"; not for chunked rows solved by the older workgroup solvers (LU below f = 96, CG at f = 112 .. 128) --
+ * otherwise an error, and cumf_sse is the way.
  */
 #define CUMF_SSE_BINS 1024
 int cumf_fused_sse_available(const cumf_plan_t* plan, int solver);

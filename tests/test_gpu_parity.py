@@ -923,33 +923,38 @@ def test_fused_lu_on_ill_conditioned_systems(oracle, alslib, f, lam):
         assert sh <= 2.0 * so + 1e-5, (stats(e_h), stats(e_o))
 
 
+@pytest.mark.parametrize("solver", ["cg", "lu"])
 @pytest.mark.parametrize("f,chunk", [(128, 0), (200, 0), (160, 64), (100, 64), (64, 32)])
-def test_fused_train_sse_cg_large_f_and_chunked_rows(oracle, alslib, f, chunk):
-    """The CG form of the fused train SSE (S - x.b - x.r - reg |x|^2) wherever the wave kernels' CG runs: the two-wave
-    kernel (f >= 112: the wave that owns the last diagonal tile reports), chunked rows (their partial tiles summed by
-    als_wave_cg_kernel, one or four waves).  Against the RMSE kernel and the oracle's fp64 sum: 2e-5 relative."""
+def test_fused_train_sse_large_f_and_chunked_rows(oracle, alslib, f, chunk, solver):
+    """The fused train SSE beyond the one-wave whole-row case.  CG (S - x.b - x.r - reg |x|^2) wherever the wave kernels'
+    CG runs: the two-wave kernel (f >= 112: the wave that owns the last diagonal tile reports), chunked rows (partial
+    tiles summed by als_wave_cg_kernel, one or four waves).  LU (the Schur complement of slot f) in lu_solve_mfma: two
+    wave roles in place (f = 128), four from the tile buffer (f = 200), chunked rows through als_reduce_kernel from
+    NB = 7 on -- below that (f = 64 with chunked rows) the thread-grid LU serves and the RMSE kernel is the way.
+    Against the RMSE kernel and the oracle's fp64 sum: 2e-5 relative."""
     _need_gpu()
     from cumf_als_amd import als
 
     r = _dataset(500, 400, 40000, 300, seed=9)
     d = r.numpy()
     rg = r.to("cuda")
-    eng = als.ALSEngine(rg, f, 0.05, solver="cg", chunk=chunk)
+    eng = als.ALSEngine(rg, f, 0.05, solver=solver, chunk=chunk)
     eng.init_factors(_factors(r.n, f, 3))
     if chunk:
         assert any(p.n_multi_rows > 0 for p in eng.t_plans)
+    expect = not (solver == "lu" and chunk and f < 96)
+    assert all(als.fused_sse_available(p, solver) for p in eng.t_plans) == expect
     for it in range(2):
         eng.update_x()
         fused = eng.update_theta_with_train_sse()
-        assert fused is not None
+        if not expect:
+            assert fused is None
+            continue
         torch.cuda.synchronize()
         kern = float(als.sse(rg.csr_data, rg.coo_row, rg.csr_indices, eng.thetaT, eng.XT).item())
         ref = oracle.sse(d["csr_data"], d["coo_row"], d["csr_indices"], eng.thetaT.cpu().numpy(), eng.XT.cpu().numpy(),
                          r.nnz, f, dtype=np.float64)
         got = float(fused.item())
-        print(f"fused train SSE (CG) f={f} chunk={chunk} iter {it}: fused {got:.6f} kernel {kern:.6f} oracle64 {ref:.6f}  "
+        print(f"fused train SSE ({solver}) f={f} chunk={chunk} iter {it}: fused {got:.6f} kernel {kern:.6f} oracle64 {ref:.6f}  "
               f"rel {abs(got - kern) / kern:.2e}")
         assert abs(got - kern) <= 2e-5 * kern and abs(got - ref) <= 2e-5 * ref, (got, kern, ref)
-    # LU at these sizes / with chunked rows is served by the RMSE kernel
-    if f > 111 or chunk:
-        assert not all(als.fused_sse_available(p, "lu") for p in eng.t_plans)
