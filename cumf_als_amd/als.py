@@ -201,6 +201,22 @@ def update_fused_sse(plan: Plan, colidx, val, gather, update, lambda_: float, so
     return bins
 
 
+def quadratic_sse_terms(A, b, x, reg, out=None):
+    """sum over the batch of 2 x.b - x^T A x + reg |x|^2 as a 1-element fp64 tensor (ADDED to `out` when given):
+    cumf_quadratic_sse_terms -- the train SSE of materialised systems is (sum r^2 of their ratings) minus it."""
+    import torch
+
+    lib = _libmod.load()
+    f = b.shape[-1]
+    batch = b.numel() // f
+    if out is None:
+        out = torch.zeros(1, dtype=torch.float64, device=b.device)
+    _libmod.check(lib.cumf_quadratic_sse_terms(_dp(A, torch.float32), _dp(b, torch.float32), _dp(x, torch.float32),
+                                               _dp(reg, torch.float32), batch, f, _dp(out, torch.float64), _stream()),
+                  "cumf_quadratic_sse_terms")
+    return out
+
+
 def get_hermitian(plan: Plan, colidx, val, gather, lambda_: float, tt=None, rhs=None, want_rhs=True, half=False):
     """Materialise the Gram batch tt[rows,f,f] (+ rhs[rows,f]) of the plan's rows (cumf_get_hermitian).
     half=True (or a float16 `tt`): fp16 storage of the Gram, cumf_get_hermitian_fp16 (als.cu:335-441)."""

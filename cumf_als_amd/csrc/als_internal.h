@@ -138,6 +138,8 @@ const void* last_item_kernel();
 hipError_t last_kernel_ms(float* item_ms, float* reduce_ms);
 // sums over every timed launch sequence since the previous call (or since timing was switched on), then resets
 hipError_t kernel_ms_since_reset(float* item_ms, float* reduce_ms, int* launches);
+hipError_t launch_quadratic_terms(const float* A, const float* b, const float* x, const float* reg, long batch, int f,
+                                  double* out, hipStream_t stream);
 hipError_t launch_sse(const float* val, const int* row, const int* col, const float* thetaT, const float* XT,
                       long count, int f, int surpass_nan, double* out, hipStream_t stream);
 

@@ -1078,6 +1078,42 @@ __global__ __launch_bounds__(kThreads) void unpack_upper_kernel(const float* __r
     A[e] = P[a * f - a * (a - 1) / 2 + (b - a)];
   }
 }
+// ----------------------------------------------------------------------------------
+// Train SSE from materialised systems (round 4; the multi-GPU `reduce` scheme, where the Gram batch is reduced across
+// ranks and solved by a batched solver): sum_u (r - x_u . t)^2 = sum r^2 - (2 t.b - t^T G t) with G = A - reg I.  One
+// workgroup per system adds 2 t.b - t^T A t + reg |t|^2 (fp64) to *out; sum r^2 is a constant of the data.  A is read by
+// columns (symmetric: y_j = sum_i A[i][j] t_i, coalesced over j).  Systems with reg == 0 (no rating) are skipped.
+// ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void quadratic_terms_kernel(const float* __restrict__ A, const float* __restrict__ b,
+                                                                   const float* __restrict__ x, const float* __restrict__ reg,
+                                                                   int f, double* __restrict__ out) {
+  __shared__ float xs[256];
+  __shared__ double red[kThreads / 64];
+  const size_t sys = blockIdx.x;
+  const float rg = reg[sys];
+  if (!(rg > 0.f)) return;  // uniform
+  const int tid = threadIdx.x;
+  if (tid < f) xs[tid] = x[sys * f + tid];
+  __syncthreads();
+  double t = 0.0;
+  if (tid < f) {
+    const float* col = A + sys * (size_t)f * f + tid;
+    float y = 0.f;
+    for (int i = 0; i < f; ++i) y = fmaf(col[(size_t)i * f], xs[i], y);
+    const float xj = xs[tid];
+    t = (double)xj * (2.0 * (double)b[sys * f + tid] - (double)y + (double)rg * (double)xj);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+  if ((tid & 63) == 0) red[tid >> 6] = t;
+  __syncthreads();
+  if (tid == 0) {
+    double sum = 0.0;
+    for (int w = 0; w < kThreads / 64; ++w) sum += red[w];
+    atomicAdd(out, sum);
+  }
+}
+
 // Gram mode "fast": factor table -> (h, l) f16 words of 4096 x (round to nearest even; als_wave.hip
 // kArithFast).  Values whose scaled magnitude leaves the f16 range (|x| >= 15.99, +-inf included) are reported
 // through *flag (bit 0); NaN entries (rows without ratings) are not.
@@ -1124,6 +1160,14 @@ hipError_t launch_pack_upper(const float* full, float* packed, long batch, int f
     hipLaunchKernelGGL(unpack_upper_kernel, dim3((unsigned)batch), dim3(kThreads), 0, stream, full, packed, f);
   else
     hipLaunchKernelGGL(pack_upper_kernel, dim3((unsigned)batch), dim3(kThreads), 0, stream, full, packed, f);
+  return hipGetLastError();
+}
+
+hipError_t launch_quadratic_terms(const float* A, const float* b, const float* x, const float* reg, long batch, int f,
+                                  double* out, hipStream_t stream) {
+  if (batch <= 0) return hipSuccess;
+  if (f > 256) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(quadratic_terms_kernel, dim3((unsigned)batch), dim3(kThreads), 0, stream, A, b, x, reg, f, out);
   return hipGetLastError();
 }
 

@@ -712,6 +712,16 @@ extern "C" int cumf_sse(const float* val, const int* row, const int* col, const 
   return 0;
 }
 
+// Train SSE from materialised systems: *sse_terms += sum over the batch of 2 x.b - x^T A x + reg[v] |x|^2 (fp64), so that
+// sum_u (r - x_u . t)^2 over the batch's ratings = (their sum r^2) - that.  A: batch x f x f (symmetric, reg[v] = lambda n_v
+// on the diagonal), b, x: batch x f, reg: batch floats; systems with reg == 0 are skipped.
+extern "C" int cumf_quadratic_sse_terms(const float* A, const float* b, const float* x, const float* reg, long batch, int f,
+                                        double* sse_terms, void* stream) {
+  if (!A || !b || !x || !reg || !sse_terms) return (int)hipErrorInvalidValue;
+  CUMF_HIP_CHECK(launch_quadratic_terms(A, b, x, reg, batch, f, sse_terms, static_cast<hipStream_t>(stream)));
+  return 0;
+}
+
 // The workgroup-per-item kernels (als_kernels.hip) address the gather table with 32-bit byte offsets
 // (Stager::gather_pass); the wave-per-item kernels use 64-bit lane addresses.  Fail loudly instead of
 // gathering garbage (VERDICT r01 / ADVICE r01: hugewiki X on one GPU is 20 GB).

@@ -121,6 +121,18 @@ class HipOps:
     def release_scratch(self) -> None:
         self.als.release_scratch()
 
+    def quad_terms(self, tt, rhs, x, reg) -> float:
+        """sum over the systems of 2 x.b - x^T A x + reg |x|^2 (cumf_quadratic_sse_terms)."""
+        if rhs.shape[0] == 0:
+            return 0.0
+        return float(self.als.quadratic_sse_terms(tt, rhs, x, reg).item())
+
+    def fused_sse_available(self, plan, solver) -> bool:
+        return self.als.fused_sse_available(plan, solver)
+
+    def update_fused_sse(self, plan, colidx, val, gather, update, lam, solver, cg_iters, bins):
+        self.als.update_fused_sse(plan, colidx, val, gather, update, lam, solver, cg_iters, bins)
+
     def get_hermitian(self, plan, colidx, val, gather, lam, tt, rhs):
         self.als.get_hermitian(plan, colidx, val, gather, lam, tt, rhs)
 
@@ -350,6 +362,7 @@ class DistALS:
             self.XT = torch.zeros((self.x_rows, f), dtype=torch.float32, device=dev)
             cp, ri, cv = local_csc_of_slab(np.asarray(rp), np.asarray(ci), np.asarray(va), self.n)
             self.lc_rowidx, self.lc_val = ops.to_device(ri), ops.to_device(cv)
+            self._lc_counts = np.diff(np.asarray(cp, dtype=np.int64))  # ratings of this slab per Theta column
             # Theta batches (als.cu:881-890), each padded to a multiple of world for the reduce-scatter
             self.t_batches = []
             for b in range(theta_batch):
@@ -404,6 +417,7 @@ class DistALS:
         per half-iteration)."""
         dev, f, w = self.thetaT.device, self.f, self.world
         self._gx = self._gt = None
+        self._sse_const = None  # (sum r^2 over all ranks, lambda * n_v per Theta column): built on first use
         if self.scheme == "gather":
             self._gx = SlabGather(self.xb, f, torch.float32, dev, self.group)
             self._gt = SlabGather(self.tb, f, torch.float32, dev, self.group)
@@ -493,6 +507,7 @@ class DistALS:
         self.x_colidx, self.x_val = colidx_l, val_l
         self.XT = torch.zeros((self.x_rows, f), dtype=torch.float32, device=dev)
         cp, self.lc_rowidx, self.lc_val = local_csc_of_slab_torch(rowptr_l, colidx_l, val_l, n)
+        self._lc_counts = np.diff(np.asarray(cp, dtype=np.int64))  # ratings of this slab per Theta column
         self.t_batches = []
         for b in range(theta_batch):
             size = n // theta_batch if b != theta_batch - 1 else n - b * (n // theta_batch)
@@ -524,7 +539,8 @@ class DistALS:
         return out
 
     # -- half-iterations -------------------------------------------------------------------
-    def _update_gathered(self, pipe, pg, gather_all, plan, colidx, val, table, out, bounds, solver, cg_iters) -> None:
+    def _update_gathered(self, pipe, pg, gather_all, plan, colidx, val, table, out, bounds, solver, cg_iters,
+                         sse_bins=None) -> None:
         """`gather` scheme, one side: this rank's slab of `out` from the replicated `table`, then the slabs of
         all ranks exchanged -- piece by piece under the next piece's kernel when a pipeline exists."""
         r0, r1 = int(bounds[self.rank]), int(bounds[self.rank + 1])
@@ -532,11 +548,17 @@ class DistALS:
         if pg is not None:
             for c, (lo, hi, piece_plan) in enumerate(pipe[1]):
                 if piece_plan is not None:
-                    self.ops.update_fused(piece_plan, colidx, val, table, mine, self.lam, solver, cg_iters)
+                    if sse_bins is not None:
+                        self.ops.update_fused_sse(piece_plan, colidx, val, table, mine, self.lam, solver, cg_iters, sse_bins)
+                    else:
+                        self.ops.update_fused(piece_plan, colidx, val, table, mine, self.lam, solver, cg_iters)
                 pg.issue(c, mine[lo:hi])
             pg.finish(out)
             return
-        self.ops.update_fused(plan, colidx, val, table, mine, self.lam, solver, cg_iters)
+        if sse_bins is not None:
+            self.ops.update_fused_sse(plan, colidx, val, table, mine, self.lam, solver, cg_iters, sse_bins)
+        else:
+            self.ops.update_fused(plan, colidx, val, table, mine, self.lam, solver, cg_iters)
         gather_all(out, mine)
 
     def update_x(self) -> None:
@@ -547,11 +569,50 @@ class DistALS:
             self.ops.update_fused(self.x_plan, self.x_colidx, self.x_val, self.thetaT, self.XT, self.lam,
                                   self.solver_x, self.cg_iters_x)
 
-    def update_theta(self) -> None:
+    # -- train SSE out of the Theta update (no pass over the ratings) ---------------------
+    def _train_sse_constants(self):
+        """(sum of r^2 over the ratings of ALL ranks, lambda * n_v for every Theta column as the reduced systems carry it
+        on their diagonal): constants of the data, built once.  `reduce` scheme only."""
+        if self._sse_const is None:
+            val = self.lc_val
+            s = torch.tensor([float((val.double() ** 2).sum().item())], dtype=torch.float64)
+            cnt = torch.from_numpy(self._lc_counts).double()
+            if dist.is_initialized() and self.world > 1:
+                if dist.get_backend() == "nccl":
+                    dev = self.XT.device
+                    s, cnt = s.to(dev), cnt.to(dev)
+                dist.all_reduce(s, group=self.group)
+                dist.all_reduce(cnt, group=self.group)
+            self._sse_const = (float(s.item()), (self.lam * cnt).float().to(self.XT.device))
+        return self._sse_const
+
+    def update_theta(self, train_sse: bool = False):
+        """update Theta.  train_sse=True: also return sum over ALL ranks of (r - x_u . theta_v)^2 over the training ratings
+        with the new Theta -- from the solved systems themselves, no pass over the ratings (None when the ops or the plans
+        cannot deliver it: the caller then runs `slab_sse`)."""
         if self.scheme == "gather":
+            bins = None
+            if train_sse:
+                ok = getattr(self.ops, "fused_sse_available", None)
+                plans = [p for (_, _, p) in self._t_pipe[1] if p is not None] if self._pt is not None else [self.t_plan]
+                if ok is None or not all(ok(p, self.solver_theta) for p in plans):
+                    train_sse = False
+                else:
+                    bins = torch.zeros(1024, dtype=torch.float64, device=self.thetaT.device)
             self._update_gathered(self._t_pipe, self._pt, self._gt, self.t_plan, self.t_colidx, self.t_val,
-                                  self.XT, self.thetaT, self.tb, self.solver_theta, self.cg_iters_theta)
-            return
+                                  self.XT, self.thetaT, self.tb, self.solver_theta, self.cg_iters_theta, bins)
+            if not train_sse:
+                return None
+            t = bins.sum().reshape(1)
+            if dist.is_initialized() and self.world > 1:
+                if dist.get_backend() != "nccl":
+                    t = t.cpu()
+                dist.all_reduce(t, group=self.group)
+            return float(t.item())
+        quad = getattr(self.ops, "quad_terms", None) if train_sse else None
+        terms = 0.0
+        if quad is not None:
+            s_total, reg_all = self._train_sse_constants()
         # reduce scheme (replaces hugewiki.cu:2611-2745).  Pipeline over the Theta batches:
         #   packed Gram(b) -> reduce-scatter(b) [async, RCCL stream]   ||   packed Gram(b + 1) ...
         #   wait(b) -> unpack -> solve(b) -> all-gather(b)
@@ -571,6 +632,10 @@ class DistALS:
                 x[: hi - lo].copy_(self.thetaT[off + lo: off + hi])          # CG warm start
                 self.ops.solve(self._my_tt[: hi - lo], self._mine_rhs[slot][: hi - lo], x[: hi - lo],
                                self.solver_theta, self.cg_iters_theta)
+                if quad is not None:  # 2 x.b - x^T A x + reg |x|^2 of this rank's systems (the solver left A, b intact)
+                    nonlocal terms
+                    terms += quad(self._my_tt[: hi - lo], self._mine_rhs[slot][: hi - lo], x[: hi - lo],
+                                  reg_all[off + lo: off + hi].contiguous())
             gathered = self._gathered[: w * k]
             all_gather_equal(gathered, x, self.group)        # replaces hugewiki.cu:2744-2745
             self.thetaT[off: off + size].copy_(gathered[:size])
@@ -593,6 +658,14 @@ class DistALS:
             pending = (bi, slot, (w1, w2))
         if pending is not None:
             finish(*pending)
+        if quad is None:
+            return None
+        t = torch.tensor([terms], dtype=torch.float64)
+        if dist.is_initialized() and self.world > 1:
+            if dist.get_backend() == "nccl":
+                t = t.to(self.XT.device)
+            dist.all_reduce(t, group=self.group)
+        return s_total - float(t.item())
 
     # -- RMSE (hugewiki.cu:2750-2862: per-GPU SSE over its slab, summed) -------------------------
     def slab_sse(self, val: torch.Tensor, row_local: torch.Tensor, col: torch.Tensor) -> float:

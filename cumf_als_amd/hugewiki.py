@@ -67,8 +67,12 @@ def run(split_dir: str, n: int, f: int, lam: float, iters: int, solver: str = "c
     t0 = time.time()
     for it in range(iters):
         eng.update_x()
-        eng.update_theta()
-        tr = (eng.slab_sse(val, train_row, colidx) / nnz) ** 0.5
+        # the train SSE out of the Theta update itself (reduced systems: sum r^2 - (2 t.b - t^T G t));
+        # the RMSE kernel over the slab's ratings (hugewiki.cu:2750-2862) only when the ops cannot deliver it
+        sse = eng.update_theta(train_sse=True)
+        if sse is None:
+            sse = eng.slab_sse(val, train_row, colidx)
+        tr = (max(sse, 0.0) / nnz) ** 0.5
         te = (eng.slab_sse(test[0], test[1], test[2]) / nnz_test) ** 0.5 if nnz_test else float("nan")
         log.append((tr, te))
         if rank == 0 and not quiet:

@@ -101,6 +101,12 @@ int cumf_als_update_fused(const cumf_plan_t* plan, const int* colidx, const floa
  */
 #define CUMF_SSE_BINS 1024
 int cumf_fused_sse_available(const cumf_plan_t* plan, int solver);
+/* The same identity on MATERIALISED systems (the multi-GPU `reduce` scheme: Gram batches reduced across GPUs and solved
+ * by cumf_*_solve_batched): *sse_terms (device, fp64) += sum over the batch of 2 x.b - x^T A x + reg[v] |x|^2, so that the
+ * squared error over the batch's ratings is (their sum r^2, a constant of the data) minus it.  A: batch x f x f fp32 with
+ * reg[v] = lambda n_v on the diagonal; systems with reg[v] == 0 (no rating) are skipped. */
+int cumf_quadratic_sse_terms(const float* A, const float* b, const float* x, const float* reg, long batch, int f,
+                             double* sse_terms, void* stream);
 int cumf_als_update_fused_sse(const cumf_plan_t* plan, const int* colidx, const float* val,
                               const float* gather, float* update, int f, float lambda, int solver,
                               int cg_iters, double* sse_bins, void* stream);

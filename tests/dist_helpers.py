@@ -58,6 +58,13 @@ class OracleOps:
         x.copy_(torch.from_numpy(np.ascontiguousarray(out, np.float32)))
 
 
+    def quad_terms(self, tt, rhs, x, reg):
+        """sum over the systems of 2 x.b - x^T A x + reg |x|^2 in fp64 (stand-in of cumf_quadratic_sse_terms)."""
+        A, b, t, rg = (v.numpy().astype(np.float64) for v in (tt, rhs, x, reg))
+        keep = rg > 0
+        q = 2.0 * (t * b).sum(1) - np.einsum("bi,bij,bj->b", t, A, t) + rg * (t * t).sum(1)
+        return float(q[keep].sum())
+
     def pack_upper(self, full, packed):
         f = full.shape[-1]
         iu = np.triu_indices(f)
@@ -123,5 +130,30 @@ def hugewiki_worker(rank, world, port, split_dir, n, f, lam, iters, solver, q):
 
         eng, log = hugewiki.run(split_dir, n, f, lam, iters, solver=solver, ops=OracleOps(), quiet=True)
         q.put((rank, eng.thetaT.numpy().copy(), eng.full_XT().numpy().copy(), log))
+    finally:
+        dist.destroy_process_group()
+
+
+def train_sse_worker(rank, world, port, solver, d, m, n, f, lam, theta_batch, theta0, q):
+    """One rank: two iterations of the `reduce` scheme, then one more Theta update that also returns the train SSE from the
+    reduced systems (DistALS.update_theta(train_sse=True)); the full factors go back for the direct evaluation."""
+    import os
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cumf_als_amd import dist as cdist
+
+        mat = cdist.HostMatrix(m, n, d["csr_indptr"], d["csr_indices"], d["csr_data"], d["csc_indptr"],
+                               d["csc_indices"], d["csc_data"])
+        eng = cdist.DistALS(mat, f, lam, OracleOps(), solver=solver, cg_iters=6, scheme="reduce", theta_batch=theta_batch)
+        eng.init_factors(theta0)
+        eng.iterate(2)
+        eng.update_x()
+        sse = eng.update_theta(train_sse=True)
+        q.put((rank, sse, eng.thetaT.numpy().copy(), eng.full_XT().numpy().copy()))
     finally:
         dist.destroy_process_group()

@@ -186,6 +186,33 @@ def test_hugewiki_runner_from_split_files(tmp_path, solver):
     assert np.abs(outs[0][1] - th0.reshape(n, f)).max() <= 2e-3 * max(1.0, np.abs(th0).max())
 
 
+@pytest.mark.parametrize("solver,theta_batch", [("lu", 1), ("cg", 3)])
+def test_reduce_scheme_train_sse_from_the_reduced_systems(oracle, solver, theta_batch):
+    """Round 4: in the `reduce` scheme the train SSE comes out of the Theta update -- sum r^2 (a constant of the data,
+    all-reduced once) minus the all-reduced sum over every rank's systems of 2 t.b - t^T G t -- instead of a pass over
+    every rank's ratings (hugewiki.cu:2750-2862).  Two ranks against the direct evaluation on the full factors."""
+    from cumf_als_amd import datagen
+
+    m, n, f, lam = 90, 40, 10, 0.05
+    r = datagen.synth_ratings(m, n, 2000, 100, seed=4, row_alpha=1.1)
+    d = {k: v for k, v in r.numpy().items()}
+    theta0 = (0.2 * np.random.RandomState(1).random_sample((n, f))).astype(np.float32)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=dist_helpers.train_sse_worker,
+                         args=(rk, 2, port, solver, d, m, n, f, lam, theta_batch, theta0, q)) for rk in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert outs[0][1] == outs[1][1]                      # the all-reduced value is the same on every rank
+    direct = oracle.sse(d["csr_data"], d["coo_row"], d["csr_indices"], outs[0][2], outs[0][3], r.nnz, f, dtype=np.float64)
+    assert abs(outs[0][1] - direct) <= 2e-5 * direct, (outs[0][1], direct)
+
+
 def test_pipeline_bounds_and_row_map():
     """The pipelined all-gather of the X update (dist.PipelinedGather): every rank's slab in nnz-balanced
     pieces, computed identically everywhere; the row map sends every global row to exactly one slot of the

@@ -232,3 +232,63 @@ def test_bench_world2_branch_runs(alslib, args, launch):
         assert len(pr[f"{side}_half_ms"]) == 2 and len(pr[f"{side}_kernel_ms"]) == 2
         for h, k, n_l in zip(pr[f"{side}_half_ms"], pr[f"{side}_kernel_ms"], pr[f"{side}_launches"]):
             assert 0 < k <= h * 1.05 and n_l >= 1, (side, h, k, n_l)
+
+
+def test_quadratic_sse_terms_kernel(alslib):
+    """cumf_quadratic_sse_terms: sum over a batch of 2 x.b - x^T A x + reg |x|^2 against numpy fp64; systems with reg == 0
+    (a column without ratings, NaN solution) are skipped."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    from cumf_als_amd import als
+
+    rng = np.random.RandomState(0)
+    for f in (10, 64, 100, 200):
+        batch = 37
+        g = rng.standard_normal((batch, f, f + 5)).astype(np.float32)
+        reg = (0.05 * rng.randint(1, 50, size=batch)).astype(np.float32)
+        A = np.einsum("bik,bjk->bij", g, g).astype(np.float32) + reg[:, None, None] * np.eye(f, dtype=np.float32)
+        b = rng.standard_normal((batch, f)).astype(np.float32)
+        x = (0.1 * rng.standard_normal((batch, f))).astype(np.float32)
+        reg[3] = 0.0
+        x[3] = np.nan
+        A64, b64, x64, r64 = (v.astype(np.float64) for v in (A, b, x, reg))
+        q = 2.0 * (x64 * b64).sum(1) - np.einsum("bi,bij,bj->b", x64, A64, x64) + r64 * (x64 * x64).sum(1)
+        want = q[reg > 0].sum()
+        got = float(als.quadratic_sse_terms(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda(), torch.from_numpy(x).cuda(),
+                                            torch.from_numpy(reg).cuda()).item())
+        scale = np.abs(q[reg > 0]).sum()
+        assert abs(got - want) <= 2e-6 * scale, (f, got, want)
+
+
+@pytest.mark.parametrize("scheme,solver", [("reduce", "lu"), ("reduce", "cg"), ("gather", "lu"), ("gather", "cg")])
+def test_distals_train_sse_out_of_the_theta_update(alslib, scheme, solver):
+    """DistALS.update_theta(train_sse=True) with the HIP ops (one rank, no process group): `reduce` -- the quadratic form of
+    the materialised systems; `gather` -- the fused kernels' own SSE (cumf_als_update_fused_sse).  Against the RMSE kernel
+    over the ratings."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    from cumf_als_amd import als, datagen
+    from cumf_als_amd import dist as cdist
+
+    f, lam = 100, 0.05
+    r = datagen.synth_ratings(3000, 800, 200000, 500, seed=2, device="cuda")
+    theta0 = (0.2 * np.random.RandomState(0).random_sample((r.n, f))).astype(np.float32)
+    ops = cdist.HipOps(torch.device("cuda"))
+    if scheme == "reduce":
+        xb = np.array([0, r.m], dtype=np.int64)
+        eng = cdist.DistALS.from_local_slab(r.m, r.n, xb, r.csr_indptr, r.csr_indices, r.csr_data, f, lam, ops, solver=solver,
+                                            theta_batch=3)
+    else:
+        eng = cdist.DistALS.from_device_ratings(r, f, lam, ops, solver=solver)
+    eng.init_factors(theta0)
+    eng.iterate(1)
+    eng.update_x()
+    got = eng.update_theta(train_sse=True)
+    assert got is not None
+    torch.cuda.synchronize()
+    want = float(als.sse(r.csr_data, r.coo_row, r.csr_indices, eng.thetaT, eng.full_XT()).item())
+    print(f"DistALS {scheme} {solver}: train SSE from the Theta update {got:.4f}, RMSE kernel {want:.4f}, rel {abs(got - want) / want:.2e}")
+    assert abs(got - want) <= 2e-5 * want, (got, want)
+    eng.close()
