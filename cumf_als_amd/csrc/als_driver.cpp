@@ -205,9 +205,20 @@ extern "C" float cumf_doALS_ex(const int* csrRowIndexHostPtr, const int* csrColI
     for (cumf_plan_t* p : st.plans) fuse_rmse = fuse_rmse && cumf_fused_sse_available(p, solver);
   }
   if (!fuse_rmse) cooRowIndex = to_device_async(cooRowIndexHostPtr, (size_t)nnz);
+  // The fused value is S - 2 t.b + t^T G t evaluated in fp32 per column: absolute error <~ 1e-7 of S = sum r^2 (measured
+  // 2e-9 .. 6e-8).  Harmless while the fit leaves a few per cent of S (Netflix: SSE / S ~ 1/15); when the fit is
+  // near-perfect the value would be mostly cancellation noise, so S is taken once (the SSE kernel with f = 0
+  // sums val^2; the index arrays are only dereferenced) and an iteration whose fused SSE falls below 1e-3 S -- where the
+  // relative error of the RMSE could pass 5e-5 -- is re-evaluated by the RMSE kernel.
+  double sum_r2 = 0.0;
+  const double kFusedSseFloor = 1e-3;
   DRV_CHECK(hipStreamSynchronize(up));
   DRV_CHECK(hipStreamDestroy(up));
   phase("uploads complete");
+  if (fuse_rmse) {
+    DRV_CHECK(cumf_sse(csrVal, csrColIndex, csrColIndex, thetaT, XT, nnz, 0, 0, d_sse, nullptr));
+    DRV_CHECK(hipMemcpy(&sum_r2, d_sse, sizeof(double), hipMemcpyDeviceToHost));
+  }
 
   auto half_iteration = [&](Side& s, const float* gather, float* update, double* sse_bins) {
     for (int b = 0; b < s.nbatch; ++b) {
@@ -274,7 +285,14 @@ extern "C" float cumf_doALS_ex(const int* csrRowIndexHostPtr, const int* csrColI
       DRV_CHECK(hipMemcpy(bins, d_bins, sizeof(bins), hipMemcpyDeviceToHost));
       sse[0] = 0.0;
       for (int i = 0; i < CUMF_SSE_BINS; ++i) sse[0] += bins[i];  // fixed order (als.cu:988: cublasSasum over the bins)
-      if (sse[0] < 0.0) sse[0] = 0.0;  // a perfect fit can come out as -1e-9 of sum r^2
+      if (!(sse[0] >= kFusedSseFloor * sum_r2)) {  // near-perfect fit (or NaN): the direct evaluation of this iteration
+        if (!cooRowIndex) {
+          DRV_CHECK(hipMalloc(reinterpret_cast<void**>(&cooRowIndex), (size_t)nnz * sizeof(int)));
+          DRV_CHECK(hipMemcpy(cooRowIndex, cooRowIndexHostPtr, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
+        }
+        DRV_CHECK(cumf_sse(csrVal, cooRowIndex, csrColIndex, thetaT, XT, nnz, f, surpass_nan, d_sse, nullptr));
+        DRV_CHECK(hipMemcpy(sse, d_sse, sizeof(double), hipMemcpyDeviceToHost));
+      }
     }
     const float rmse_train = (float)sqrt(sse[0] / (double)nnz);
     final_rmse = (float)sqrt(sse[1] / (double)nnz_test);

@@ -1082,7 +1082,8 @@ __global__ __launch_bounds__(kThreads) void unpack_upper_kernel(const float* __r
 // Train SSE from materialised systems (round 4; the multi-GPU `reduce` scheme, where the Gram batch is reduced across
 // ranks and solved by a batched solver): sum_u (r - x_u . t)^2 = sum r^2 - (2 t.b - t^T G t) with G = A - reg I.  One
 // workgroup per system adds 2 t.b - t^T A t + reg |t|^2 (fp64) to *out; sum r^2 is a constant of the data.  A is read by
-// columns (symmetric: y_j = sum_i A[i][j] t_i, coalesced over j).  Systems with reg == 0 (no rating) are skipped.
+// columns (symmetric: y_j = sum_i A[i][j] t_i, coalesced over j).  Systems with reg < 0 (the caller's mark for "no rating": its solution is NaN) are skipped;
+// reg == 0 is a valid system (lambda = 0).
 // ----------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void quadratic_terms_kernel(const float* __restrict__ A, const float* __restrict__ b,
                                                                    const float* __restrict__ x, const float* __restrict__ reg,
@@ -1091,7 +1092,7 @@ __global__ __launch_bounds__(kThreads) void quadratic_terms_kernel(const float* 
   __shared__ double red[kThreads / 64];
   const size_t sys = blockIdx.x;
   const float rg = reg[sys];
-  if (!(rg > 0.f)) return;  // uniform
+  if (!(rg >= 0.f)) return;  // uniform: negative (or NaN) = no rating
   const int tid = threadIdx.x;
   if (tid < f) xs[tid] = x[sys * f + tid];
   __syncthreads();
@@ -1644,7 +1645,10 @@ hipError_t launch_half_iteration(const KernelArgs& a, int mode, long n_items, lo
     // A plan with a FEW chunked rows (a Theta side with a handful of very long columns): their chunk items go first, in a
     // launch of their own, and the whole rows keep the instance without the dump exit (no spilled accumulators, VERDICT r03
     // weak 7).  When the chunks are most of the work (the Netflix X side: 86 % of the ratings) one combined launch stays:
-    // the whole rows fill the tail of the equal-sized chunk items, worth more than the spills cost.
+    // the whole rows fill the tail of the equal-sized chunk items, worth more than the spills cost.  (Round 5 measured
+    // the alternative for that side too -- the chunk items through the dump-only instance, 0 spilled registers, one after
+    // the other or side by side on a second stream: 6.83 / 6.82 ms against 6.69-6.85 combined, same box,
+    // profiles/r05/stage_variants_ab.txt: the 63 spilled registers of the combined instance cost nothing measurable.)
     KernelArgs ac = a;
     long n_chunk_first = 0;
     if (mode == kModeLU && n_mrows > 0 && lists != nullptr && lists->n_citems > 0 && lists->n_witems > 0 &&

@@ -590,9 +590,10 @@ extern "C" int cumf_als_update_fused(const cumf_plan_t* p, const int* colidx, co
   return update_fused_impl(p, colidx, val, gather, update, f, lambda, solver, cg_iters, nullptr, stream);
 }
 
-// Can the half-iteration of this plan also deliver the train SSE of its rows (cumf_als_update_fused_sse)?  LU: when every
-// row is solved inside the wave-per-item kernel (16 <= f <= 111, no chunked row).  CG: wherever the wave kernels' CG runs
-// (16 <= f <= 207, see below).  Never in gram mode "exact" (workgroup kernels).
+// Can the half-iteration of this plan also deliver the train SSE of its rows (cumf_als_update_fused_sse)?  Wherever the
+// wave kernels' solvers run (16 <= f <= 207, gram mode not "exact"), whole rows and chunked rows alike, with two gaps -- the
+// chunked rows of LU plans below f = 96 and of CG plans at f = 112 .. 128 go to the older workgroup solvers (the matrix
+// below spells out which solver takes which rows).
 extern "C" int cumf_fused_sse_available(const cumf_plan_t* p, int solver) {
   if (!p) return 0;
   const int mode = solver == CUMF_SOLVER_LU ? kModeLU : kModeCG;
@@ -714,7 +715,7 @@ extern "C" int cumf_sse(const float* val, const int* row, const int* col, const 
 
 // Train SSE from materialised systems: *sse_terms += sum over the batch of 2 x.b - x^T A x + reg[v] |x|^2 (fp64), so that
 // sum_u (r - x_u . t)^2 over the batch's ratings = (their sum r^2) - that.  A: batch x f x f (symmetric, reg[v] = lambda n_v
-// on the diagonal), b, x: batch x f, reg: batch floats; systems with reg == 0 are skipped.
+// on the diagonal), b, x: batch x f, reg: batch floats; a system without ratings is marked by reg < 0 and skipped.
 extern "C" int cumf_quadratic_sse_terms(const float* A, const float* b, const float* x, const float* reg, long batch, int f,
                                         double* sse_terms, void* stream) {
   if (!A || !b || !x || !reg || !sse_terms) return (int)hipErrorInvalidValue;

@@ -375,6 +375,102 @@ __device__ __forceinline__ void gram_mfma(const Planes<NB>& P, f32x4 (&acc)[NB *
 }
 
 // ----------------------------------------------------------------------------------
+// Diagonal tiles at four products instead of six (round 5).  On tile (I, I) both operands come from the same feature
+// block, so mh = (hm)^T and lh = (hl)^T: the tile accumulates D + 2 S with D = hh + mm (symmetric) and S = h m^T + h l^T
+// -- two MFMAs whose A operand is the h plane with every exponent raised by one (2 h: one v_pk_add_u16 per register,
+// exact) -- and ONCE per item, after the last stage, (T + T^T) / 2 = D + S + S^T restores the tile (wave_symmetrise_diag:
+// a 16 x 16 transpose through the idle stage buffer).  2 NB of the 6 NT MFMAs of every stage go: 14 of 168 at f = 100.
+// The doubled plane lives for three MFMAs: [2h l^T on (I, I)] [an independent tile] [2h m^T on (I, I)].
+// Exponent + 1 on a bf16 zero gives 2^-126 -- multiplied by the m / l of a zero value, which are zero; an Inf / NaN still
+// reaches the accumulator through hh.
+// ----------------------------------------------------------------------------------
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x4 bf16x8_times2(u32x4 v) {
+  u32x4 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned w = v[e];  // through a scalar first: __builtin_bit_cast applied to a vector-element lvalue reads element 0
+    r[e] = __builtin_bit_cast(unsigned, (u16x2)(__builtin_bit_cast(u16x2, w) + u16x2{0x0080, 0x0080}));
+  }
+  return r;
+}
+enum { kLH = 0, kHL = 1, kMM = 2, kMH = 3, kHM = 4, kHH = 5, kD2L = 6, kD2M = 7 };
+template <int NB>
+struct GramSched {
+  static constexpr int NT = NB * (NB + 1) / 2;
+  static constexpr int N = 6 * NT - 2 * NB;
+  int tile[N], kind[N];
+};
+template <int NB>
+__host__ __device__ constexpr GramSched<NB> make_gram_sched() {
+  constexpr int NT = NB * (NB + 1) / 2, NOFF = NT - NB;
+  GramSched<NB> s{};
+  int off[NOFF > 0 ? NOFF : 1] = {}, dg[NB] = {};
+  int no = 0, nd = 0;
+  for (int t = 0; t < NT; ++t) {
+    if (tile_I<NB>(t) == tile_J<NB>(t)) dg[nd++] = t; else off[no++] = t;
+  }
+  int n = 0;
+  for (int k = 0; k < NOFF; ++k) { s.tile[n] = off[k]; s.kind[n++] = kLH; }
+  for (int k = 0; k < NOFF; ++k) { s.tile[n] = off[k]; s.kind[n++] = kHL; }
+  int used = 0;  // off-diagonal mm products spent as separators inside the diagonal triples
+  for (int I = 0; I < NB; ++I) {
+    s.tile[n] = dg[I]; s.kind[n++] = kD2L;
+    if (used < NOFF) { s.tile[n] = off[used++]; s.kind[n++] = kMM; }
+    s.tile[n] = dg[I]; s.kind[n++] = kD2M;
+  }
+  for (int k = used; k < NOFF; ++k) { s.tile[n] = off[k]; s.kind[n++] = kMM; }
+  for (int I = 0; I < NB; ++I) { s.tile[n] = dg[I]; s.kind[n++] = kMM; }
+  for (int k = 0; k < NOFF; ++k) { s.tile[n] = off[k]; s.kind[n++] = kMH; }
+  for (int k = 0; k < NOFF; ++k) { s.tile[n] = off[k]; s.kind[n++] = kHM; }
+  for (int t = 0; t < NT; ++t) { s.tile[n] = t; s.kind[n++] = kHH; }
+  return s;
+}
+template <int NB, int N>
+__device__ __forceinline__ void gram_mfma_sched(const Planes<NB>& P, f32x4 (&acc)[NB * (NB + 1) / 2], u32x4& h2) {
+  constexpr GramSched<NB> S = make_gram_sched<NB>();
+  constexpr int t = S.tile[N], kind = S.kind[N];
+  constexpr int I = tile_I<NB>(t), J = tile_J<NB>(t);
+  if constexpr (kind == kLH) acc[t] = mfma_bf16(P.l[I], P.h[J], acc[t]);
+  if constexpr (kind == kHL) acc[t] = mfma_bf16(P.h[I], P.l[J], acc[t]);
+  if constexpr (kind == kMM) acc[t] = mfma_bf16(P.m[I], P.m[J], acc[t]);
+  if constexpr (kind == kMH) acc[t] = mfma_bf16(P.m[I], P.h[J], acc[t]);
+  if constexpr (kind == kHM) acc[t] = mfma_bf16(P.h[I], P.m[J], acc[t]);
+  if constexpr (kind == kHH) acc[t] = mfma_bf16(P.h[I], P.h[J], acc[t]);
+  if constexpr (kind == kD2L) {
+    h2 = bf16x8_times2(P.h[I]);
+    acc[t] = mfma_bf16(h2, P.l[I], acc[t]);
+  }
+  if constexpr (kind == kD2M) acc[t] = mfma_bf16(h2, P.m[I], acc[t]);
+}
+// (T + T^T) / 2 on the diagonal tiles, once per item: lane (g, c) register r holds T[4 g + r][c]; every tile goes through
+// its own 16 x 17 window of the wave's stage buffer (idle: the last stage prefetches nothing; LDS operations of one wave
+// execute in order).  A diagonal entry comes back as itself.
+// NW waves per item: wave W holds tile t in slot t / NW when t % NW == W and restores its own diagonal tiles.
+template <int NB, int NW = 1, int W = 0>
+__device__ __forceinline__ void wave_symmetrise_diag(f32x4 (&acc)[(NB * (NB + 1) / 2 + NW - 1) / NW], float* win, int lane) {
+  const int c = lane & 15, g = lane >> 4;
+  static_for<NB>([&](auto ic) {
+    constexpr int I = decltype(ic)::value;
+    constexpr int t = tile_of<NB>(I, I);
+    if constexpr (t % NW == W) {
+      float* w = win + I * 16 * 17;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w[(4 * g + r) * 17 + c] = acc[t / NW][r];
+    }
+  });
+  static_for<NB>([&](auto ic) {
+    constexpr int I = decltype(ic)::value;
+    constexpr int t = tile_of<NB>(I, I);
+    if constexpr (t % NW == W) {
+      const float* w = win + I * 16 * 17;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[t / NW][r] = 0.5f * (acc[t / NW][r] + w[c * 17 + 4 * g + r]);
+    }
+  });
+}
+
+// ----------------------------------------------------------------------------------
 // One stage, sized for TWO waves per SIMD (<= 256 registers per lane).  A wave cannot hide its own
 // VALU work behind its own 16-cycle MFMAs (measured: stage time = MFMA time + VALU time with one
 // wave per SIMD, whatever the interleave), so the overlap comes from the partner wave: this
@@ -383,6 +479,10 @@ __device__ __forceinline__ void gram_mfma(const Planes<NB>& P, f32x4 (&acc)[NB *
 // (global_load_lds: no registers in flight) before the split + MFMAs of this one:
 //   wait for the chunks of stage s -> registers -> issue the chunks of stage s + 1 -> split ->
 //   6 NT MFMAs.
+// (Program order, not issue order: the compiler's scheduler sinks most of the LDS-DMA instructions behind the MFMA burst.
+// Round 5 pinned them in front of the split (sched_barrier) and interleaved them with it (sched_group_barrier): no
+// gain either way -- X side 6.75-6.87 vs 6.69-6.85 ms, Theta side 10.75-11.06 vs 10.52-10.60, same box,
+// profiles/r05/stage_variants_ab.txt -- the partner wave covers the gather latency; the tree keeps the compiler's order.)
 // ----------------------------------------------------------------------------------
 template <int NB, int PROD, int ARITH>
 __device__ __forceinline__ void gram_product(const Planes<NB, ARITH>& P, f32x4 (&acc)[NB * (NB + 1) / 2]) {
@@ -424,7 +524,12 @@ __device__ __forceinline__ void stage_step(const WaveGather<NB>& wg, Planes<NB, 
       wg.template load_idx<false>(R, s_idx);
   }
   static_for<4 * NB>([&](auto uc) { split_pair<NB, decltype(uc)::value / 4, decltype(uc)::value % 4>(R, P); });
-  static_for<gram_products<ARITH>()>([&](auto pc) { gram_product<NB, decltype(pc)::value>(P, acc); });
+  if constexpr (ARITH == kArithSplit3) {
+    u32x4 h2 = {0u, 0u, 0u, 0u};
+    static_for<GramSched<NB>::N>([&](auto nc) { gram_mfma_sched<NB, decltype(nc)::value>(P, acc, h2); });
+  } else {
+    static_for<gram_products<ARITH>()>([&](auto pc) { gram_product<NB, decltype(pc)::value>(P, acc); });
+  }
 }
 
 // ----------------------------------------------------------------------------------
@@ -675,7 +780,7 @@ __device__ __forceinline__ float fma_quad_bcast(float t, float n, float acc) {
 // quad lane kk and reach lane group kk with four ds_bpermute.  ~30 VALU per panel instead of ~66.
 template <int NB, int Ip, int q, bool DYN, int STEP>
 __device__ __forceinline__ void lu_prep_step_s(const f32x4 (&acc)[NB * (NB + 1) / 2], LuPrepS<NB>& s, float (&w)[NB], float& wm,
-                                               float* rdiag, int f, const LuLaneS& ln) {
+                                               float* rdiag, int f, const LuLaneS& ln, int dbg = 0) {
   constexpr int L = NB - Ip;
   constexpr int SD = tile_of<NB>(Ip, Ip);
   constexpr int p0 = 16 * Ip + 4 * q;
@@ -697,6 +802,13 @@ __device__ __forceinline__ void lu_prep_step_s(const f32x4 (&acc)[NB * (NB + 1) 
     constexpr int t = tile_of<NB>(Ip, b);
     const int src = 4 * (16 * q + ln.c);  // byte address of lane (q, c)
     // (the element goes through a float first: __builtin_bit_cast applied to a vector-element lvalue reads element 0)
+#if CUMF_ABLATE
+    // profiling build: 4096 / 8192 = the panel rows of the blocks right of the diagonal tile without their broadcast
+    if ((dbg & (4096 | 8192)) && b > Ip) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s.R[b][r] = acc[t][r];
+    } else
+#endif
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float v = acc[t][r];
@@ -743,6 +855,15 @@ __device__ __forceinline__ void lu_prep_step_s(const f32x4 (&acc)[NB * (NB + 1) 
     rdiag[p0 + ln.kk] = -(s.rsk * s.rsk);
   } else {
     constexpr int b = Ip + STEP - (L + 8);
+#if CUMF_ABLATE
+    // profiling build: 8192 = the eliminated rows of the blocks right of the diagonal tile by ONE fp32 MFMA on the
+    // accumulator registers (what a stride-4 pivot order would issue; wrong values here)
+    if ((dbg & 8192) && b > Ip) {
+      const f32x4 z = __builtin_amdgcn_mfma_f32_16x16x4f32(s.e0 * s.rsk, acc[tile_of<NB>(Ip, b)][q], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      w[b] = z[0];
+      return;
+    }
+#endif
     const float un = fmaf(ln.e3c, s.R[b][3], fmaf(s.e2, s.R[b][2], fmaf(s.e1, s.R[b][1], s.e0 * s.R[b][0])));  // -u_k at block b
     w[b] = un * s.rsk;  // the sign is immaterial: w meets itself
     if constexpr (b == Ip) wm = sel(ln.c > 4 * q + ln.kk, w[b], 0.f);  // rows at or above the pivot stay
@@ -854,7 +975,11 @@ __device__ __forceinline__ float lu_wave_blocked(f32x4 (&acc)[NB * (NB + 1) / 2]
             constexpr int n = n0 + decltype(nc)::value;
             lu_trailing_mfma<NB, lu_trailing_tile<NB, Ip + 1>(n % NTl), n / NTl>(acc, h, m, l);
           });
+#if CUMF_ABLATE
+          lu_prep_step_s<NB, Ip, q, dynp, i>(acc, s, w[q], wm, rdiag, f, ln, dbg);
+#else
           lu_prep_step_s<NB, Ip, q, dynp, i>(acc, s, w[q], wm, rdiag, f, ln);
+#endif
           if constexpr (TP > 0) __builtin_amdgcn_sched_barrier(0);
         });
         // the block row's own tiles: what its next panel reads (and the rows the back substitution reads later)
@@ -1281,6 +1406,12 @@ __global__ __launch_bounds__(64, CUMF_WAVE_MIN_WAVES) void als_wave_kernel(const
     stage_step<NB, kStepLast, ARITH>(wg, P, R, lds, lds_lane, acc, 0, 0);  // the last stage prefetches nothing
   }
   if constexpr (ARITH == kArithFast) fast_unscale<NB, 1, 0>(acc, a.fast_flag);
+  if constexpr (ARITH == kArithSplit3) {
+#if CUMF_ABLATE
+    if (!(a.dbg & 2))
+#endif
+      wave_symmetrise_diag<NB>(acc, smem, lane);
+  }
 
   if constexpr (!WHOLE) {
     if (slot >= 0) {
@@ -1405,6 +1536,12 @@ __device__ __forceinline__ void multi_body(float* smem, const KernelArgs& a, lon
               if constexpr (PROD == 0) acc[sl] = mfma_f16(P.l[I], P.h[J], acc[sl]);
               if constexpr (PROD == 1) acc[sl] = mfma_f16(P.h[I], P.l[J], acc[sl]);
               if constexpr (PROD == 2) acc[sl] = mfma_f16(P.h[I], P.h[J], acc[sl]);
+            } else if constexpr (I == J) {
+              // diagonal tile: D + 2 S in four products (see make_gram_sched), restored behind the last stage
+              if constexpr (PROD == 1) acc[sl] = mfma_bf16(bf16x8_times2(P.h[I]), P.l[I], acc[sl]);
+              if constexpr (PROD == 2) acc[sl] = mfma_bf16(P.m[I], P.m[I], acc[sl]);
+              if constexpr (PROD == 4) acc[sl] = mfma_bf16(bf16x8_times2(P.h[I]), P.m[I], acc[sl]);
+              if constexpr (PROD == 5) acc[sl] = mfma_bf16(P.h[I], P.h[I], acc[sl]);
             } else {
               if constexpr (PROD == 0) acc[sl] = mfma_bf16(P.l[I], P.h[J], acc[sl]);
               if constexpr (PROD == 1) acc[sl] = mfma_bf16(P.h[I], P.l[J], acc[sl]);
@@ -1419,6 +1556,10 @@ __device__ __forceinline__ void multi_body(float* smem, const KernelArgs& a, lon
     }
   }
   if constexpr (ARITH == kArithFast) fast_unscale<NB, NW, W>(acc, a.fast_flag);
+  if constexpr (ARITH == kArithSplit3) {
+    __syncthreads();  // the partner is done with the last stage's chunks: the transposition windows alias the stage buffers
+    wave_symmetrise_diag<NB, NW, W>(acc, smem, lane);
+  }
   // a whole row (no slot): the two waves solve it where the tiles are -- 93 KB per row at f = 200 that
   // neither go out to HBM nor come back (measured: 45 GB each way per Netflix X half-iteration)
   if (slot < 0) {

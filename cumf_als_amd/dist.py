@@ -121,11 +121,12 @@ class HipOps:
     def release_scratch(self) -> None:
         self.als.release_scratch()
 
-    def quad_terms(self, tt, rhs, x, reg) -> float:
-        """sum over the systems of 2 x.b - x^T A x + reg |x|^2 (cumf_quadratic_sse_terms)."""
-        if rhs.shape[0] == 0:
-            return 0.0
-        return float(self.als.quadratic_sse_terms(tt, rhs, x, reg).item())
+    def quad_terms(self, tt, rhs, x, reg, acc) -> None:
+        """acc (1-element fp64 device tensor) += sum over the systems of 2 x.b - x^T A x + reg |x|^2
+        (cumf_quadratic_sse_terms; reg < 0 marks a system without ratings).  No host synchronisation: the Theta pipeline
+        keeps its Gram(b + 1) || reduce-scatter(b) overlap."""
+        if rhs.shape[0] > 0:
+            self.als.quadratic_sse_terms(tt, rhs, x, reg, out=acc)
 
     def fused_sse_available(self, plan, solver) -> bool:
         return self.als.fused_sse_available(plan, solver)
@@ -418,6 +419,7 @@ class DistALS:
         dev, f, w = self.thetaT.device, self.f, self.world
         self._gx = self._gt = None
         self._sse_const = None  # (sum r^2 over all ranks, lambda * n_v per Theta column): built on first use
+        self._fused_sse_ok = {}  # solver -> every RANK's Theta plans deliver the fused train SSE (decided collectively, once)
         if self.scheme == "gather":
             self._gx = SlabGather(self.xb, f, torch.float32, dev, self.group)
             self._gt = SlabGather(self.tb, f, torch.float32, dev, self.group)
@@ -583,8 +585,29 @@ class DistALS:
                     s, cnt = s.to(dev), cnt.to(dev)
                 dist.all_reduce(s, group=self.group)
                 dist.all_reduce(cnt, group=self.group)
-            self._sse_const = (float(s.item()), (self.lam * cnt).float().to(self.XT.device))
+            # lambda n_v; -1 marks a column without ratings anywhere (its solution is NaN and must not enter the sum) --
+            # not "reg == 0", which is every column when lambda = 0
+            reg = torch.where(cnt > 0, self.lam * cnt, torch.full_like(cnt, -1.0))
+            self._sse_const = (float(s.item()), reg.float().to(self.XT.device))
         return self._sse_const
+
+    def _fused_sse_everywhere(self) -> bool:
+        """`gather` scheme: can the fused kernels of EVERY rank deliver the train SSE of their Theta slab?  Availability
+        depends on the plan (a slab with one chunked heavy column is refused for LU below f = 96 or CG at f = 112..128),
+        so the ranks may differ -- and a rank that skipped the all-reduce of the bins while the others performed it would
+        pair its next collective with theirs.  Decided once per solver by an all-reduce (MIN) of the flag."""
+        key = self.solver_theta
+        if key not in self._fused_sse_ok:
+            ok = getattr(self.ops, "fused_sse_available", None)
+            plans = [p for (_, _, p) in self._t_pipe[1] if p is not None] if self._pt is not None else [self.t_plan]
+            mine = ok is not None and all(ok(p, self.solver_theta) for p in plans)
+            flag = torch.tensor([1 if mine else 0], dtype=torch.int32)
+            if dist.is_initialized() and self.world > 1:
+                if dist.get_backend() == "nccl":
+                    flag = flag.to(self.thetaT.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            self._fused_sse_ok[key] = bool(int(flag.item()))
+        return self._fused_sse_ok[key]
 
     def update_theta(self, train_sse: bool = False):
         """update Theta.  train_sse=True: also return sum over ALL ranks of (r - x_u . theta_v)^2 over the training ratings
@@ -593,9 +616,7 @@ class DistALS:
         if self.scheme == "gather":
             bins = None
             if train_sse:
-                ok = getattr(self.ops, "fused_sse_available", None)
-                plans = [p for (_, _, p) in self._t_pipe[1] if p is not None] if self._pt is not None else [self.t_plan]
-                if ok is None or not all(ok(p, self.solver_theta) for p in plans):
+                if not self._fused_sse_everywhere():  # the same answer on every rank: no collective is skipped one-sidedly
                     train_sse = False
                 else:
                     bins = torch.zeros(1024, dtype=torch.float64, device=self.thetaT.device)
@@ -610,9 +631,10 @@ class DistALS:
                 dist.all_reduce(t, group=self.group)
             return float(t.item())
         quad = getattr(self.ops, "quad_terms", None) if train_sse else None
-        terms = 0.0
+        terms = None
         if quad is not None:
             s_total, reg_all = self._train_sse_constants()
+            terms = torch.zeros(1, dtype=torch.float64, device=self.XT.device)  # accumulated on the device, read once
         # reduce scheme (replaces hugewiki.cu:2611-2745).  Pipeline over the Theta batches:
         #   packed Gram(b) -> reduce-scatter(b) [async, RCCL stream]   ||   packed Gram(b + 1) ...
         #   wait(b) -> unpack -> solve(b) -> all-gather(b)
@@ -633,9 +655,8 @@ class DistALS:
                 self.ops.solve(self._my_tt[: hi - lo], self._mine_rhs[slot][: hi - lo], x[: hi - lo],
                                self.solver_theta, self.cg_iters_theta)
                 if quad is not None:  # 2 x.b - x^T A x + reg |x|^2 of this rank's systems (the solver left A, b intact)
-                    nonlocal terms
-                    terms += quad(self._my_tt[: hi - lo], self._mine_rhs[slot][: hi - lo], x[: hi - lo],
-                                  reg_all[off + lo: off + hi].contiguous())
+                    quad(self._my_tt[: hi - lo], self._mine_rhs[slot][: hi - lo], x[: hi - lo],
+                         reg_all[off + lo: off + hi].contiguous(), terms)
             gathered = self._gathered[: w * k]
             all_gather_equal(gathered, x, self.group)        # replaces hugewiki.cu:2744-2745
             self.thetaT[off: off + size].copy_(gathered[:size])
@@ -660,10 +681,10 @@ class DistALS:
             finish(*pending)
         if quad is None:
             return None
-        t = torch.tensor([terms], dtype=torch.float64)
+        t = terms
         if dist.is_initialized() and self.world > 1:
-            if dist.get_backend() == "nccl":
-                t = t.to(self.XT.device)
+            if dist.get_backend() != "nccl":
+                t = t.cpu()
             dist.all_reduce(t, group=self.group)
         return s_total - float(t.item())
 
@@ -691,8 +712,20 @@ class DistALS:
             check()
 
     def close(self) -> None:
-        """Hand the library's pooled scratch of this device back (tile buffers of the f >= 144 LU path, pre-split tables of
-        gram mode "fast": up to 48 GiB outside torch's caching allocator)."""
+        """Destroy the plans (the side plans, the pipeline pieces', the Theta batches') and hand the library's pooled scratch
+        of this device back (tile buffers of the f >= 144 LU path, pre-split tables of gram mode "fast": up to 48 GiB
+        outside torch's caching allocator)."""
+        plans = [getattr(self, "x_plan", None), getattr(self, "t_plan", None)]
+        for pipe in (getattr(self, "_x_pipe", None), getattr(self, "_t_pipe", None)):
+            if pipe is not None:
+                plans += [p for (_, _, p) in pipe[1]]
+        plans += [p for (_, _, p) in getattr(self, "t_batches", [])]
+        for p in plans:
+            if p is not None and hasattr(p, "close"):
+                p.close()
+        self.x_plan = self.t_plan = None
+        self._x_pipe = self._t_pipe = None
+        self.t_batches = []
         release = getattr(self.ops, "release_scratch", None)
         if release is not None:
             release()

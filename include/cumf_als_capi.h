@@ -97,14 +97,17 @@ int cumf_als_update_fused(const cumf_plan_t* plan, const int* colidx, const floa
  * memory, zeroed by the caller, ADDED to (fp64 atomics); the SSE is their sum.  Only when
  * cumf_fused_sse_available(plan, solver) -- wherever the wave kernels' solvers run: 16 <= f <= 207, gram mode not
  * "exact"; not for chunked rows solved by the older workgroup solvers (LU below f = 96, CG at f = 112 .. 128) --
- * otherwise an error, and cumf_sse is the way.
+ * otherwise an error, and cumf_sse is the way.  Accuracy: fp32 per column, absolute error <~ 1e-7 of the columns' sum r^2
+ * (measured 2e-9 .. 6e-8), i.e. relative error <~ 1e-7 (sum r^2 / SSE): callers that may meet near-perfect fits compare
+ * the result with sum r^2 and fall back on cumf_sse below ~1e-3 of it, as doALS does.
  */
 #define CUMF_SSE_BINS 1024
 int cumf_fused_sse_available(const cumf_plan_t* plan, int solver);
 /* The same identity on MATERIALISED systems (the multi-GPU `reduce` scheme: Gram batches reduced across GPUs and solved
  * by cumf_*_solve_batched): *sse_terms (device, fp64) += sum over the batch of 2 x.b - x^T A x + reg[v] |x|^2, so that the
  * squared error over the batch's ratings is (their sum r^2, a constant of the data) minus it.  A: batch x f x f fp32 with
- * reg[v] = lambda n_v on the diagonal; systems with reg[v] == 0 (no rating) are skipped. */
+ * reg[v] = lambda n_v on the diagonal; a system WITHOUT ratings (its solution is NaN) is marked by reg[v] < 0 and skipped
+ * (reg[v] == 0 is a valid system: lambda = 0). */
 int cumf_quadratic_sse_terms(const float* A, const float* b, const float* x, const float* reg, long batch, int f,
                              double* sse_terms, void* stream);
 int cumf_als_update_fused_sse(const cumf_plan_t* plan, const int* colidx, const float* val,
@@ -229,7 +232,7 @@ int cumf_last_kernel_name(char* buf, int cap);
  * convention -- print and exit, als.h:628-665 -- is kept for HIP failures only).  Reading clears it. */
 enum { CUMF_ERR_FAST_RANGE = 10001 };
 int cumf_last_error(void);
-/* Frees the scratch the library keeps between calls on the CURRENT device (tile buffers of the f >= 160 LU,
+/* Frees the scratch the library keeps between calls on the CURRENT device (tile buffers of the f >= 144 LU,
  * pre-split tables of gram mode "fast"; one per device and stream, grow-only).  Safe against other host threads:
  * it waits for entry points that are mid-sequence on this device and leaves other devices' buffers alone.
  * doALS calls it before returning. */

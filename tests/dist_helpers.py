@@ -58,12 +58,13 @@ class OracleOps:
         x.copy_(torch.from_numpy(np.ascontiguousarray(out, np.float32)))
 
 
-    def quad_terms(self, tt, rhs, x, reg):
-        """sum over the systems of 2 x.b - x^T A x + reg |x|^2 in fp64 (stand-in of cumf_quadratic_sse_terms)."""
+    def quad_terms(self, tt, rhs, x, reg, acc):
+        """acc += sum over the systems of 2 x.b - x^T A x + reg |x|^2 in fp64 (stand-in of cumf_quadratic_sse_terms;
+        reg < 0 marks a system without ratings)."""
         A, b, t, rg = (v.numpy().astype(np.float64) for v in (tt, rhs, x, reg))
-        keep = rg > 0
+        keep = rg >= 0
         q = 2.0 * (t * b).sum(1) - np.einsum("bi,bij,bj->b", t, A, t) + rg * (t * t).sum(1)
-        return float(q[keep].sum())
+        acc += float(q[keep].sum())
 
     def pack_upper(self, full, packed):
         f = full.shape[-1]
@@ -83,6 +84,60 @@ class OracleOps:
             return 0.0
         return float(pyoracle.sse(val.numpy(), row.numpy(), col.numpy(), thetaT.numpy(), XT.numpy(),
                                   val.numel(), thetaT.shape[-1]))
+
+
+class OracleSseOps(OracleOps):
+    """OracleOps + the fused train SSE of the `gather` scheme (stand-in of cumf_als_update_fused_sse /
+    cumf_fused_sse_available); `available` is this rank's answer for its own plans."""
+
+    def __init__(self, available=True):
+        self.available = available
+
+    def fused_sse_available(self, plan, solver):
+        return self.available
+
+    def update_fused_sse(self, plan, colidx, val, gather, update, lam, solver, cg_iters, bins):
+        assert self.available, "a rank whose plans cannot deliver the fused SSE must not be asked for it"
+        self.update_fused(plan, colidx, val, gather, update, lam, solver, cg_iters)
+        b, e = plan.row_begin, plan.row_end
+        rp = plan.rowptr.astype(np.int64)
+        rows = np.repeat(np.arange(b, e), np.diff(rp[b:e + 1]))
+        s0, s1 = int(rp[b]), int(rp[e])
+        pred = (update.numpy()[rows].astype(np.float64) * gather.numpy()[colidx.numpy()[s0:s1]].astype(np.float64)).sum(1)
+        bins[0] += float(((val.numpy()[s0:s1].astype(np.float64) - pred) ** 2).sum())
+
+
+def gather_sse_worker(rank, world, port, solver, d, m, n, f, lam, theta0, unavailable_rank, q):
+    """One rank of the `gather` scheme asking for the train SSE out of the Theta update; rank `unavailable_rank`'s plans
+    refuse it (-1: none does).  A refused request must come back as None on EVERY rank, and the fallback `slab_sse` (one
+    all-reduce of its own) must then pair up across the ranks."""
+    import os
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cumf_als_amd import dist as cdist
+
+        mat = cdist.HostMatrix(m, n, d["csr_indptr"], d["csr_indices"], d["csr_data"], d["csc_indptr"],
+                               d["csc_indices"], d["csc_data"])
+        eng = cdist.DistALS(mat, f, lam, OracleSseOps(available=rank != unavailable_rank), solver=solver, cg_iters=6,
+                            scheme="gather")
+        eng.init_factors(theta0)
+        eng.iterate(1)
+        eng.update_x()
+        fused = eng.update_theta(train_sse=True)
+        x0, x1 = int(eng.xb[rank]), int(eng.xb[rank + 1])
+        rp = np.asarray(d["csr_indptr"], np.int64)
+        rows = np.repeat(np.arange(x1 - x0), np.diff(rp[x0:x1 + 1]))
+        sl = slice(int(rp[x0]), int(rp[x1]))
+        direct = eng.slab_sse(torch.from_numpy(np.ascontiguousarray(d["csr_data"][sl])), torch.from_numpy(rows),
+                              torch.from_numpy(np.ascontiguousarray(d["csr_indices"][sl])))
+        q.put((rank, fused, direct))
+    finally:
+        dist.destroy_process_group()
 
 
 def worker(rank, world, port, scheme, solver, d, m, n, f, lam, iters, theta_batch, theta0, q, ops_kind="oracle",

@@ -213,6 +213,36 @@ def test_reduce_scheme_train_sse_from_the_reduced_systems(oracle, solver, theta_
     assert abs(outs[0][1] - direct) <= 2e-5 * direct, (outs[0][1], direct)
 
 
+@pytest.mark.parametrize("unavailable_rank", [-1, 1])
+def test_gather_scheme_train_sse_is_decided_collectively(oracle, unavailable_rank):
+    """in the `gather` scheme the fused train SSE depends on each rank's own plans.  When only ONE
+    rank's plans refuse it, every rank must fall back together (update_theta returns None everywhere) -- a rank that
+    skipped the all-reduce of the bins alone would pair its next collective with the others' and hang or sum nonsense."""
+    from cumf_als_amd import datagen
+
+    m, n, f, lam = 90, 40, 10, 0.05
+    r = datagen.synth_ratings(m, n, 2000, 100, seed=4, row_alpha=1.1)
+    d = {k: v for k, v in r.numpy().items()}
+    theta0 = (0.2 * np.random.RandomState(1).random_sample((n, f))).astype(np.float32)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=dist_helpers.gather_sse_worker,
+                         args=(rk, 2, port, "lu", d, m, n, f, lam, theta0, unavailable_rank, q)) for rk in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, fused0, direct0), (_, fused1, direct1) = outs
+    assert direct0 == direct1 and direct0 > 0           # the fall-back's own all-reduce paired up
+    if unavailable_rank < 0:
+        assert fused0 == fused1 and abs(fused0 - direct0) <= 1e-6 * direct0, (fused0, direct0)
+    else:
+        assert fused0 is None and fused1 is None, (fused0, fused1)
+
+
 def test_pipeline_bounds_and_row_map():
     """The pipelined all-gather of the X update (dist.PipelinedGather): every rank's slab in nnz-balanced
     pieces, computed identically everywhere; the row map sends every global row to exactly one slot of the

@@ -232,11 +232,21 @@ def test_bench_world2_branch_runs(alslib, args, launch):
         assert len(pr[f"{side}_half_ms"]) == 2 and len(pr[f"{side}_kernel_ms"]) == 2
         for h, k, n_l in zip(pr[f"{side}_half_ms"], pr[f"{side}_kernel_ms"], pr[f"{side}_launches"]):
             assert 0 < k <= h * 1.05 and n_l >= 1, (side, h, k, n_l)
+    # the default N > 1 line (Netflix shape, strong scaling) also carries the configuration the 8-GPU
+    # target is defined on -- the hugewiki slab per GPU, `reduce` scheme, weak scaling -- as `hugewiki`
+    if "hugewiki" in args:
+        assert "hugewiki" not in line
+    else:
+        hw = line["hugewiki"]
+        assert hw["scaling"] == "weak" and hw["scheme"] == "reduce" and hw["n_ranks_seen"] == 2 and hw["theta_batch"] == 3
+        assert hw["value"] > 0 and np.isfinite(hw["value"]) and hw["ms_per_step"] > 0
+        assert hw["x_half_ms"] > 0 and hw["theta_half_ms"] > 0 and set(hw["non_kernel_ms"]) == {"x", "theta"}
+        assert len(hw["per_rank"]["x_half_ms"]) == 2 and "configs[3]" in hw["workload"]
 
 
 def test_quadratic_sse_terms_kernel(alslib):
-    """cumf_quadratic_sse_terms: sum over a batch of 2 x.b - x^T A x + reg |x|^2 against numpy fp64; systems with reg == 0
-    (a column without ratings, NaN solution) are skipped."""
+    """cumf_quadratic_sse_terms: sum over a batch of 2 x.b - x^T A x + reg |x|^2 against numpy fp64; systems marked with reg < 0
+    (a column without ratings, NaN solution) are skipped, reg == 0 (lambda = 0) is a system like any other."""
     torch = pytest.importorskip("torch")
     if not torch.cuda.is_available():
         pytest.fail("-m gpu tests need a GPU")
@@ -250,14 +260,16 @@ def test_quadratic_sse_terms_kernel(alslib):
         A = np.einsum("bik,bjk->bij", g, g).astype(np.float32) + reg[:, None, None] * np.eye(f, dtype=np.float32)
         b = rng.standard_normal((batch, f)).astype(np.float32)
         x = (0.1 * rng.standard_normal((batch, f))).astype(np.float32)
-        reg[3] = 0.0
+        reg[3] = -1.0
         x[3] = np.nan
+        A[5] -= reg[5] * np.eye(f, dtype=np.float32)
+        reg[5] = 0.0
         A64, b64, x64, r64 = (v.astype(np.float64) for v in (A, b, x, reg))
         q = 2.0 * (x64 * b64).sum(1) - np.einsum("bi,bij,bj->b", x64, A64, x64) + r64 * (x64 * x64).sum(1)
-        want = q[reg > 0].sum()
+        want = q[reg >= 0].sum()
         got = float(als.quadratic_sse_terms(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda(), torch.from_numpy(x).cuda(),
                                             torch.from_numpy(reg).cuda()).item())
-        scale = np.abs(q[reg > 0]).sum()
+        scale = np.abs(q[reg >= 0]).sum()
         assert abs(got - want) <= 2e-6 * scale, (f, got, want)
 
 

@@ -106,8 +106,9 @@ def _check_rows_against_oracle(oracle, indptr, indices, data, gather, warm, got,
         to 6e-2 (measured on the Netflix-shape Theta side: fp32-vs-fp64 1e-5 after 3 iterations, 4e-2 after 6;
         SURVEY 7.3-3).  The yardstick is therefore the fp64 oracle and the allowance the fp32 oracle's own spread,
         as distributions over the sampled rows: median, 99th percentile and maximum of the HIP rows' element-wise
-        distance from the fp64 iterate <= max(2e-4, 2 x the same statistic of the fp32 oracle), and the same for
-        the relative residual ||A x - b|| / ||b|| (floor 1e-4): HIP is as good a CG(6) as the reference's fp32."""
+        distance from the fp64 iterate <= 1 x the same statistic of the fp32 oracle + 1e-5 (round 5: the allowance of the
+        LU rows; rounds 3-4 allowed max(2e-4, 2 x)), and the same for the relative residual ||A x - b|| / ||b||: HIP is
+        as good a CG(6) as the reference's fp32."""
     x32, sub = _oracle_rows(oracle, indptr, indices, data, gather, warm, rows, f, lam, solver, cg_iters=cg_iters)
     xh = got[torch.from_numpy(rows).to(got.device)].cpu().numpy()
     assert np.array_equal(np.isnan(xh), np.isnan(x32)), what
@@ -136,10 +137,10 @@ def _check_rows_against_oracle(oracle, indptr, indices, data, gather, warm, got,
     stats = lambda v: (float(np.median(v)), float(np.quantile(v, 0.99)), float(v.max()))
     print(f"{what} CG({cg_iters}): rows {len(rows)}  |x - x64| (median, q99, max): hip {stats(e_h)}  oracle32 {stats(e_o)}  "
           f"| rel. residual: hip {stats(res[0])}  oracle32 {stats(res[1])}  oracle64 {stats(res[2])}")
-    for sh, so in zip(stats(e_h), stats(e_o)):
-        assert sh <= max(2e-4, 2.0 * so), (what, stats(e_h), stats(e_o))
+    for sh, so in zip(stats(e_h), stats(e_o)):  # 1 x the fp32 oracle's own statistic (round 5; rounds 3-4: max(2e-4, 2 x))
+        assert sh <= so + 1e-5, (what, stats(e_h), stats(e_o))
     for sh, so in zip(stats(res[0]), stats(res[1])):
-        assert sh <= max(1e-4, 2.0 * so), (what, stats(res[0]), stats(res[1]))
+        assert sh <= so + 1e-5, (what, stats(res[0]), stats(res[1]))
 
 
 @pytest.mark.parametrize("f,solver", [(100, "cg"), (100, "lu"), (64, "lu"), (64, "cg"), (200, "cg"), (200, "lu"),
@@ -456,19 +457,29 @@ def _doals_cxx_symbol(alslib, d, thetaT, XT, m, n, f, nnz, nnz_test, lam, iters,
     return float(rm), np.stack([tr, te], axis=1), text
 
 
+ITERS_REFERENCE = 10  # main.cpp:17
+
+
 @pytest.mark.parametrize("solver", ["lu", "cg"])
 def test_headline_doals_rmse_log_matches_oracle(oracle, alslib, solver):
-    """VERDICT r03 item 1 / north_star "RMSE to 1e-4 on the same inputs": the reference's loop (als.cu:727-1022: update
-    X, update Theta, train RMSE :979-991, test RMSE :1006-1019) for THREE full iterations at the headline shape
-    (17 770 x 480 189, 99 072 112 ratings, f = 100, lambda = 0.048) with the reference's own batch setting
-    X_BATCH = 1, THETA_BATCH = 3 (test_als.sh:16) through the C++ symbol doALS, against oracle_doALS on the same
-    matrix, the same srand(0) initial factors (main.cpp:72-78), the same truncated test grid (als.cu:1006).
-    Train and test RMSE of every iteration within 1e-4; LU: the factors of the last iteration too."""
+    """VERDICT r03 item 1 / r04 next 3 / north_star "RMSE to 1e-4 on the same inputs": the reference's loop (als.cu:727-1022:
+    update X, update Theta, train RMSE :979-991, test RMSE :1006-1019) for the reference's own run length ITERS = 10
+    (main.cpp:17) at the headline shape (17 770 x 480 189, 99 072 112 ratings, f = 100, lambda = 0.048) with the
+    reference's own batch setting X_BATCH = 1, THETA_BATCH = 3 (test_als.sh:16) through the C++ symbol doALS, against
+    oracle_doALS on the same matrix, the same srand(0) initial factors (main.cpp:72-78), the same truncated test grid
+    (als.cu:1006).  Train and test RMSE of all ten iterations within 1e-4 (LU: 2e-5).
+    Where a deviation comes from is measured, not argued: (i) the same ten iterations with the RMSE KERNEL instead of the
+    train SSE out of the Theta update (CUMF_ALS_RMSE=kernel): bit-identical factors, and the difference of the two logs is
+    the fused SSE's share; (ii) the train RMSE of the final factors re-evaluated in fp64 on the CPU: what each of the three
+    reported values (HIP fused, HIP kernel, the fp32 oracle with its 1 000 fp32 bins on ITS factors) misses it by.
+    LU: the factors after three iterations against the same loop evaluated in fp64 (r04)."""
     _need_gpu()
-    from cumf_als_amd import datagen
+    import os
+
+    from cumf_als_amd import als, datagen
 
     shp = datagen.SHAPES["netflix"]
-    m, n, nnz, nnz_test, lam, iters = shp["m"], shp["n"], shp["nnz"], shp["nnz_test"], shp["lam"], 3
+    m, n, nnz, nnz_test, lam, iters = shp["m"], shp["n"], shp["nnz"], shp["nnz_test"], shp["lam"], ITERS_REFERENCE
     r = datagen.synth_ratings(m, n, nnz, nnz_test, seed=0, device="cuda")
     d = r.numpy()
     del r
@@ -477,14 +488,52 @@ def test_headline_doals_rmse_log_matches_oracle(oracle, alslib, solver):
     th_h, x_h = th0.copy(), x0.copy()
     rm_h, log_h, text = _doals_cxx_symbol(alslib, d, th_h, x_h, m, n, F, nnz, nnz_test, lam, iters, 1, 3, solver)
     assert ("CG solver with fp32." in text) == (solver == "cg")
+
+    def hip(n_it, rmse_mode):
+        keep = os.environ.get("CUMF_ALS_RMSE")
+        if rmse_mode:
+            os.environ["CUMF_ALS_RMSE"] = rmse_mode
+        try:
+            th, x, rm, log = als.do_als(d["csr_indptr"], d["csr_indices"], d["csr_data"], d["csc_indices"], d["csc_indptr"],
+                                        d["csc_data"], d["coo_row"], d["test_row"], d["test_col"], d["test_data"], m, n, F,
+                                        nnz, nnz_test, lam, n_it, 1, 3, 0, thetat_init=th0, xt_init=x0, solver=solver,
+                                        return_log=True)
+        finally:
+            if keep is None:
+                os.environ.pop("CUMF_ALS_RMSE", None)
+            else:
+                os.environ["CUMF_ALS_RMSE"] = keep
+        return th, x, np.asarray(log, np.float64)
+
+    th_f, x_f, log_f = hip(iters, None)        # train SSE out of the Theta update (the default)
+    th_k, x_k, log_k = hip(iters, "kernel")    # the RMSE kernel over the 99 M ratings, as the reference
+    assert np.array_equal(th_f, th_k, equal_nan=True) and np.array_equal(x_f, x_k, equal_nan=True)
+    assert np.array_equal(th_f, th_h, equal_nan=True)                     # ... and the C++ symbol ran the same thing
+    assert np.abs(log_f - log_h).max() <= 1e-6                            # (its log is printed with six decimals)
+    share = np.abs(log_f - log_k)
+    th_h3, x_h3, _ = hip(3, None)
+
     th_o, x_o = th0.copy(), x0.copy()
-    rm_o, log_o = oracle.do_als(d, th_o, x_o, m, n, F, lam, iters, x_batch=1, theta_batch=3, solver=solver)
+    _, log_a = oracle.do_als(d, th_o, x_o, m, n, F, lam, 3, x_batch=1, theta_batch=3, solver=solver)
+    th_o3, x_o3 = th_o.copy(), x_o.copy()
+    rm_o, log_b = oracle.do_als(d, th_o, x_o, m, n, F, lam, iters - 3, x_batch=1, theta_batch=3, solver=solver)  # continues
+    log_o = np.concatenate([log_a, log_b])
     dlog = np.abs(log_h - log_o)
-    print(f"headline doALS {solver}: hip log {log_h.tolist()}  oracle log {log_o.tolist()}  max |d| {dlog.max():.3e}  "
-          f"final {rm_h:.7f} vs {rm_o:.7f}")
-    assert dlog.max() <= 1e-4, (log_h, log_o)
-    assert abs(rm_h - rm_o) <= 1e-4
+    exact = lambda th, x: float(np.sqrt(oracle.sse(d["csr_data"], d["coo_row"], d["csr_indices"], th, x, nnz, F,
+                                                   dtype=np.float64) / nnz))
+    ex_h, ex_o = exact(th_f, x_f), exact(th_o, x_o)
+    miss = {"hip_fused": abs(log_f[-1, 0] - ex_h), "hip_kernel": abs(log_k[-1, 0] - ex_h), "oracle32": abs(log_o[-1, 0] - ex_o)}
+    print(f"headline doALS {solver}, {iters} iterations: hip log {log_h.tolist()}  oracle log {log_o.tolist()}  max |d| per "
+          f"iteration {dlog.max(1).tolist()}  final {rm_h:.7f} vs {rm_o:.7f};  fused-vs-kernel log (same factors, bit for bit): "
+          f"train {share[:, 0].max():.2e} test {share[:, 1].max():.2e};  hip-kernel log vs oracle {np.abs(log_k - log_o).max():.2e};  "
+          f"final train RMSE re-evaluated in fp64 on the CPU: hip factors {ex_h:.8f} oracle factors {ex_o:.8f}; reported minus "
+          f"re-evaluated: {miss}")
+    assert dlog.max() <= (2e-5 if solver == "lu" else 1e-4), (log_h, log_o)
+    assert abs(rm_h - rm_o) <= (2e-5 if solver == "lu" else 1e-4)
+    assert share[:, 1].max() == 0.0 and share[:, 0].max() <= 1e-5        # the fused train SSE's share of any deviation
+    assert miss["hip_fused"] <= 1e-5 and miss["hip_kernel"] <= 2e-6
     assert np.array_equal(np.isnan(th_h), np.isnan(th_o)) and np.array_equal(np.isnan(x_h), np.isnan(x_o))
+    th_h, x_h, th_o, x_o = th_h3, x_h3, th_o3, x_o3   # the factor statistics below: after three iterations, as in round 4
     ft, fx = np.isfinite(th_o), np.isfinite(x_o)
 
     def dist(a, b, fin):
@@ -495,7 +544,7 @@ def test_headline_doals_rmse_log_matches_oracle(oracle, alslib, solver):
     stats = lambda v: (float(np.median(v)), float(np.quantile(v, 0.99)), float(v.max()))
     e_t, row_t = dist(th_h, th_o, ft)
     e_x, row_x = dist(x_h, x_o, fx)
-    print(f"headline doALS {solver}: factors after {iters} iterations vs the fp32 oracle, max-abs relative: Theta {e_t:.3e}  "
+    print(f"headline doALS {solver}: factors after 3 iterations vs the fp32 oracle, max-abs relative: Theta {e_t:.3e}  "
           f"X {e_x:.3e}; per-row relative (median, q99, max): Theta {stats(row_t)}  X {stats(row_x)}")
     if solver == "lu":
         # Three iterations of an unpivoted fp32 LU on rows of up to 2 x 10^5 ratings: the fp32 oracle's own sequential
@@ -504,13 +553,13 @@ def test_headline_doals_rmse_log_matches_oracle(oracle, alslib, solver):
         # the typical row and no farther from it than the fp32 oracle is (median, 99th percentile, maximum + 1e-5),
         # and within 1e-3 of the fp32 oracle everywhere.
         th_64, x_64 = th0.copy(), x0.copy()
-        _, log_64 = oracle.do_als(d, th_64, x_64, m, n, F, lam, iters, x_batch=1, theta_batch=3, solver=solver,
+        _, log_64 = oracle.do_als(d, th_64, x_64, m, n, F, lam, 3, x_batch=1, theta_batch=3, solver=solver,
                                   dtype=np.float64)
         h_t, h_x = dist(th_h, th_64, ft)[1], dist(x_h, x_64, fx)[1]
         o_t, o_x = dist(th_o, th_64, ft)[1], dist(x_o, x_64, fx)[1]
         print(f"headline doALS lu: per-row relative distance from the fp64 oracle (median, q99, max): Theta hip {stats(h_t)} "
               f"oracle32 {stats(o_t)}  X hip {stats(h_x)} oracle32 {stats(o_x)};  RMSE log vs fp64: hip "
-              f"{np.abs(log_h - log_64).max():.3e} oracle32 {np.abs(log_o - log_64).max():.3e}")
+              f"{np.abs(log_h[:3] - log_64).max():.3e} oracle32 {np.abs(log_o[:3] - log_64).max():.3e}")
         assert np.median(h_t) <= 1e-4 and np.median(h_x) <= 1e-4, (stats(h_t), stats(h_x))
         for sh, so in zip(stats(h_t) + stats(h_x), stats(o_t) + stats(o_x)):
             assert sh <= so + 1e-5, (stats(h_t), stats(o_t), stats(h_x), stats(o_x))

@@ -587,11 +587,13 @@ def test_fused_half_iteration(oracle, alslib, gram_mode, solver, f):
         else:
             # CG(6): the tolerance lives on the residual.  After the same <= 6 iterations the HIP
             # iterate is as good a solution as the oracle's: ||A x - b|| within 1e-4 ||b|| of the oracle's, per
-            # system; residuals below the stopping threshold sqrt(CG_ERROR) = 1e-2 (cg.cu:31,195) are
-            # interchangeable (an iterate that stops one step earlier is still below it)
+            # system -- no absolute floor (round 5) except where the stopping rule itself makes two iterates
+            # interchangeable: the loop leaves as soon as ||r||^2 < CG_ERROR = 1e-4 (cg.cu:31,195), so when BOTH final
+            # residuals are below sqrt(CG_ERROR) = 1e-2 one of the two may simply have stopped a step earlier
             res_h = np.linalg.norm(np.einsum("bij,bj->bi", A64, xh.astype(np.float64)) - b64, axis=1)
-            assert (np.abs(res_h - res_o) <= 1e-4 * np.linalg.norm(b64, axis=1) + 1e-2).all(), \
-                (chunk, np.abs(res_h - res_o).max())
+            close = np.abs(res_h - res_o) <= 1e-4 * np.linalg.norm(b64, axis=1) + 1e-6
+            both_stopped = np.maximum(res_h, res_o) <= 1.05e-2
+            assert (close | both_stopped).all(), (chunk, np.abs(res_h - res_o)[~(close | both_stopped)].max())
             assert err <= 5e-4 * max(1.0, np.abs(x_o).max()), (chunk, err)
 
 
@@ -849,6 +851,40 @@ def test_doals_rmse_log_fused_vs_kernel(alslib):
         print(f"doALS {solver}: fused log {log_a[:, 0].tolist()} kernel log {log_b[:, 0].tolist()}")
         assert np.abs(log_a - log_b).max() <= 2e-6 * max(1.0, np.abs(log_b).max()), (log_a, log_b)
         assert rm_a == rm_b
+
+
+def test_doals_fused_rmse_near_perfect_fit_is_reevaluated(alslib):
+    """the fused train SSE is sum r^2 - 2 t.b + t^T G t in fp32 -- fine while the fit leaves a few per cent of
+    sum r^2, mostly cancellation noise when the fit is near-perfect.  doALS takes sum r^2 once and hands an iteration whose
+    fused SSE falls below 1e-3 of it to the RMSE kernel: on noise-free rank-4 ratings with a tiny lambda every logged train
+    RMSE must agree with the all-kernel run (CUMF_ALS_RMSE=kernel) to 2e-4 RELATIVE although the last ones are below 1e-2
+    of the ratings' rms."""
+    _need_gpu()
+    import os
+
+    from cumf_als_amd import als, datagen
+
+    m, n, nnz, nnz_test, f, lam = 600, 500, 60000, 2000, 16, 1e-7
+    r = datagen.synth_ratings(m, n, nnz, nnz_test, seed=3, rank=4, noise=0.0)
+    d = r.numpy()
+    th0 = _factors(n, f, 2)
+
+    def run():
+        return als.do_als(d["csr_indptr"], d["csr_indices"], d["csr_data"], d["csc_indices"], d["csc_indptr"], d["csc_data"],
+                          d["coo_row"], d["test_row"], d["test_col"], d["test_data"], m, n, f, r.nnz, r.nnz_test, lam, 8, 1, 1,
+                          0, thetat_init=th0, solver="lu", return_log=True)
+
+    th_a, x_a, _, log_a = run()
+    os.environ["CUMF_ALS_RMSE"] = "kernel"
+    try:
+        th_b, x_b, _, log_b = run()
+    finally:
+        del os.environ["CUMF_ALS_RMSE"]
+    np.testing.assert_array_equal(th_a, th_b)
+    rms_rating = float(np.sqrt((d["csr_data"].astype(np.float64) ** 2).mean()))
+    print(f"near-perfect fit: rms rating {rms_rating:.4f}  fused log {log_a[:, 0].tolist()}  kernel log {log_b[:, 0].tolist()}")
+    assert log_b[-1, 0] <= 1e-2 * rms_rating, log_b        # the regime the fall-back exists for: SSE < 1e-4 sum r^2
+    assert (np.abs(log_a[:, 0] - log_b[:, 0]) <= 2e-4 * log_b[:, 0] + 1e-7).all(), (log_a, log_b)
 
 
 def test_few_chunked_rows_take_the_split_launch(oracle, alslib):

@@ -21,17 +21,25 @@ def main() -> int:
     ap.add_argument("--extra", type=int, nargs="*", default=[],
                     help="further solve-only runs with these LU ablation bits OR-ed to 2 (256 no panel preparation, 512 no fp32 "
                          "MFMAs, 1024 no trailing update, 2048 no back substitution)")
+    ap.add_argument("--raw", type=int, nargs="*", default=[], help="further runs with exactly these switch values")
+    ap.add_argument("--only", default="", help="run just this variant (full / gram_only / solve_only): for counter passes, whose "
+                    "per-kernel means must not mix the variants; the warm-up iteration then runs with the other solver")
     a = ap.parse_args()
     shp = datagen.SHAPES["netflix"]
     r = datagen.synth_ratings(shp["m"], shp["n"], shp["nnz"], shp["nnz_test"], seed=0, device="cuda")
     eng = als.ALSEngine(r, a.f, shp["lam"], solver=a.solver)
     eng.init_factors()
     als.set_debug_switches(0)
+    if a.only:
+        eng.solver = "cg" if a.solver == "lu" else "lu"
     eng.iterate(1)
+    eng.solver = a.solver
     keep_x, keep_t = eng.XT.clone(), eng.thetaT.clone()
     out = {"library": os.path.basename(os.environ.get("CUMF_ALS_LIB", "libALS.so")), "f": a.f, "solver": a.solver}
     als.set_kernel_timing(True)
-    for sw, name in [(0, "full"), (1, "gram_only"), (2, "solve_only")] + [(2 | e, f"solve_only+{e}") for e in a.extra]:
+    for sw, name in [(0, "full"), (1, "gram_only"), (2, "solve_only")] + [(2 | e, f"solve_only+{e}") for e in a.extra] + [(v, f"switches_{v}") for v in a.raw]:
+        if a.only and name != a.only:
+            continue
         als.set_debug_switches(sw)
         xs, ts = [], []
         for _ in range(a.reps + 1):
