@@ -361,9 +361,12 @@ def make_slab_engine(a, shp, world, rank, dev, f, lam, theta0, solver, cg_iters,
     xb = np.arange(world + 1, dtype=np.int64) * r.m
     # THETA_BATCH = 3 as the reference's hugewiki run (hugewiki.cu:27-41): with more than one rank the
     # reduce-scatter of batch b runs under the partial-Gram pass of batch b + 1
+    # --reference-solvers: the per-side solvers of the reference's own hugewiki run -- X by CG with 100 iterations
+    # (hugewiki.cu:2569), Theta by the batched LU on the reduced Grams (hugewiki.cu:2732)
+    sides = dict(solver_x="cg", cg_iters_x=100, solver_theta="lu") if getattr(a, "reference_solvers", False) else {}
     eng = cdist.DistALS.from_local_slab(m, n, xb, r.csr_indptr, r.csr_indices, r.csr_data, f, lam, cdist.HipOps(dev),
                                         solver=solver, cg_iters=cg_iters,
-                                        theta_batch=theta_batch if theta_batch > 0 else (3 if world > 1 else 1))
+                                        theta_batch=theta_batch if theta_batch > 0 else (3 if world > 1 else 1), **sides)
     eng.init_factors(theta0)
     return eng, r, m, nnz
 
@@ -457,6 +460,8 @@ def main() -> int:
                          "has no PMC pass of the dispatched kernel")
     ap.add_argument("--no-gram-leg", action="store_true",
                     help="skip the Gram-pass-alone leg (profiling runs: its solve-less launches would skew per-kernel averages)")
+    ap.add_argument("--reference-solvers", action="store_true",
+                    help="--shape hugewiki: X by CG(100), Theta by LU, as the reference's hugewiki run (hugewiki.cu:2569,2732)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hugewiki-leg", action="store_true",
                     help="N > 1: skip the hugewiki-slab leg (weak scaling, reduce scheme) behind the default Netflix one")
@@ -616,7 +621,9 @@ def main() -> int:
             "config": {"workload": f"{a.shape}-shape synthetic ratings {m}x{n}, nnz={nnz}, f={f}, "
                                    f"lambda={lam}, solver={a.solver}"
                                    + (f"(cg_iters={a.cg_iters})" if a.solver == "cg" else "")
-                                   + (f", row slab per GPU (1/8 hugewiki), reduce scheme over {world} GPU(s)" if slab_mode
+                                   + (f", row slab per GPU (1/8 hugewiki), reduce scheme over {world} GPU(s)"
+                                      + (", X by CG(100) / Theta by LU (hugewiki.cu:2569,2732)" if a.reference_solvers else "")
+                                      if slab_mode
                                       else ", X_BATCH=1 THETA_BATCH=1, fused Gram+solve" if world == 1
                                       else f", {a.scheme} scheme over {world} GPUs"),
                        "step": "update-X + update-Theta (two half-iterations)", "gen_seconds": round(t_gen, 2)},

@@ -227,11 +227,8 @@ __device__ __forceinline__ void lu_solve_mfma(LuAcc<NB, NW>& acc, float* __restr
         if constexpr (t < NT) {
           if constexpr (tile_I<NB>(t) == Ip) {
             constexpr int J = tile_J<NB>(t);
-            if (kk == q) {
-              float* xp = X + ((p0 >> 2) & 1) * 4 * LuLds<NB>::kXRow + 16 * J + c;
-#pragma unroll
-              for (int r = 0; r < 4; ++r) xp[r * LuLds<NB>::kXRow] = acc[s][r];
-            }
+            if (kk == q)  // the four rows of a column side by side: ONE 16-byte store here, one 16-byte load per reader
+              *reinterpret_cast<f32x4*>(X + ((p0 >> 2) & 1) * 4 * LuLds<NB>::kXRow + 4 * (16 * J + c)) = acc[s];
           }
         }
       });
@@ -291,10 +288,7 @@ __device__ __forceinline__ void lu_solve_mfma(LuAcc<NB, NW>& acc, float* __restr
       }
       __syncthreads();
       if constexpr (lu_wave_live<NB, NW>(W, Ip)) {
-      const float* xb = X + ((p0 >> 2) & 1) * 4 * LuLds<NB>::kXRow;
-      const float* r0p = xb;
-      const float* r1p = xb + LuLds<NB>::kXRow;
-      const float* r2p = xb + 2 * LuLds<NB>::kXRow;
+      const float* xb = X + ((p0 >> 2) & 1) * 4 * LuLds<NB>::kXRow + 4 * c;
       if constexpr (W != OWNER) {
         const f32x4 line = *reinterpret_cast<const f32x4*>(tab + 4 * kk);
         c0 = line[0];
@@ -302,14 +296,20 @@ __device__ __forceinline__ void lu_solve_mfma(LuAcc<NB, NW>& acc, float* __restr
         c2 = line[2];
         nrp = line[3];
       }
-      // 2b. eliminated panel row of this lane group at every live block: three FMAs per block
-      const float* rkp = xb + kk * LuLds<NB>::kXRow;
+      // 2b. eliminated panel row of this lane group at every live block: three FMAs per block.  Round 5: the four raw
+      // rows of a column arrive in ONE ds_read_b128 (4 LDS cycles, against 4 x 2 for four ds_read_b32 and a quarter of the
+      // instructions: this LU is bound by the CU's LDS pipe -- 4 660 LDS instructions per 200 x 200 system, round 3)
+      const bool k1 = kk == 1, k2 = kk == 2, k3 = kk == 3;
       float ub[NB];
       static_for<NB>([&](auto bc) {
         constexpr int b = decltype(bc)::value;
         if constexpr (lu_needs_block<NB, NW>(W, Ip, b)) {
-          const float own = rkp[16 * b + c];
-          const float a0 = r0p[16 * b + c], a1 = r1p[16 * b + c], a2 = r2p[16 * b + c];
+          const f32x4 rr = *reinterpret_cast<const f32x4*>(xb + 64 * b);
+          const float a0 = rr[0], a1 = rr[1], a2 = rr[2];
+          float own = a0;  // this lane group's own raw row (flat selects)
+          own = k1 ? a1 : own;
+          own = k2 ? a2 : own;
+          own = k3 ? rr[3] : own;
           // lanes of a pivot past f (short last panel) keep a finite dummy: their A operand is 0
           ub[b] = fmaf(c2, a2, fmaf(c1, a1, fmaf(c0, a0, own)));
         }

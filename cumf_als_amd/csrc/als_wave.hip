@@ -44,13 +44,11 @@
 
 #include "als_device.h"
 #include "als_lu_wg.h"
+#include "als_lu_blocked.h"
 #include "als_internal.h"
 
 namespace cumf {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4u __attribute__((ext_vector_type(4), aligned(4)));
@@ -67,28 +65,6 @@ constexpr int kZeroFloats = 256; // >= 16 * kMaxWaveNB + 16
 // Zeros that stand in for "no rating here": ratings past the end of an item gather from
 // this row, the pad lanes of the last feature block read it too.
 static __device__ float g_wave_zeros[kZeroFloats];
-
-// two fp32 -> packed bf16x2 (a in the low half), round to nearest even: v_cvt_pk_bf16_f32
-__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
-  f32x2 v = {a, b};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-__device__ __forceinline__ float bf16_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
-__device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
-// x - (low / high bf16 of p), exact whenever the difference is representable (it is for the residuals of
-// the split): one v_dot2c_f32_bf16 (x += p.lo * s.lo + p.hi * s.hi with s = (-1, 0) / (0, -1)) instead of
-// unpack + subtract.  The selector pairs sit in SGPRs: as immediates the compiler emits the inline
-// constant -1.0, which the instruction does not read as the bf16 pair (tools/probes/dot2_probe.hip).
-__device__ __forceinline__ float sub_bf16_lo(float x, unsigned p) {
-  unsigned sel;
-  asm("s_mov_b32 %0, 0xbf80" : "=s"(sel));
-  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, p), __builtin_bit_cast(bf16x2, sel), x, false);
-}
-__device__ __forceinline__ float sub_bf16_hi(float x, unsigned p) {
-  unsigned sel;
-  asm("s_mov_b32 %0, 0xbf800000" : "=s"(sel));
-  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, p), __builtin_bit_cast(bf16x2, sel), x, false);
-}
 
 __device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
@@ -426,8 +402,11 @@ __host__ __device__ constexpr GramSched<NB> make_gram_sched() {
   for (int t = 0; t < NT; ++t) { s.tile[n] = t; s.kind[n++] = kHH; }
   return s;
 }
+// h2: the doubled plane, two copies used in turn by successive feature blocks -- the block that is doubled next never
+// writes the registers the MFMA just issued still reads (the 128-bit operands of this MFMA are read over more than one
+// cycle: als_lu_rows.h, mfma_bf16_k32).
 template <int NB, int N>
-__device__ __forceinline__ void gram_mfma_sched(const Planes<NB>& P, f32x4 (&acc)[NB * (NB + 1) / 2], u32x4& h2) {
+__device__ __forceinline__ void gram_mfma_sched(const Planes<NB>& P, f32x4 (&acc)[NB * (NB + 1) / 2], u32x4 (&h2)[2]) {
   constexpr GramSched<NB> S = make_gram_sched<NB>();
   constexpr int t = S.tile[N], kind = S.kind[N];
   constexpr int I = tile_I<NB>(t), J = tile_J<NB>(t);
@@ -438,35 +417,30 @@ __device__ __forceinline__ void gram_mfma_sched(const Planes<NB>& P, f32x4 (&acc
   if constexpr (kind == kHM) acc[t] = mfma_bf16(P.h[I], P.m[J], acc[t]);
   if constexpr (kind == kHH) acc[t] = mfma_bf16(P.h[I], P.h[J], acc[t]);
   if constexpr (kind == kD2L) {
-    h2 = bf16x8_times2(P.h[I]);
-    acc[t] = mfma_bf16(h2, P.l[I], acc[t]);
+    h2[I & 1] = bf16x8_times2(P.h[I]);
+    acc[t] = mfma_bf16(h2[I & 1], P.l[I], acc[t]);
   }
-  if constexpr (kind == kD2M) acc[t] = mfma_bf16(h2, P.m[I], acc[t]);
+  if constexpr (kind == kD2M) acc[t] = mfma_bf16(h2[I & 1], P.m[I], acc[t]);
 }
 // (T + T^T) / 2 on the diagonal tiles, once per item: lane (g, c) register r holds T[4 g + r][c]; every tile goes through
 // its own 16 x 17 window of the wave's stage buffer (idle: the last stage prefetches nothing; LDS operations of one wave
 // execute in order).  A diagonal entry comes back as itself.
-// NW waves per item: wave W holds tile t in slot t / NW when t % NW == W and restores its own diagonal tiles.
-template <int NB, int NW = 1, int W = 0>
-__device__ __forceinline__ void wave_symmetrise_diag(f32x4 (&acc)[(NB * (NB + 1) / 2 + NW - 1) / NW], float* win, int lane) {
+template <int NB>
+__device__ __forceinline__ void wave_symmetrise_diag(f32x4 (&acc)[NB * (NB + 1) / 2], float* win, int lane) {
   const int c = lane & 15, g = lane >> 4;
   static_for<NB>([&](auto ic) {
     constexpr int I = decltype(ic)::value;
     constexpr int t = tile_of<NB>(I, I);
-    if constexpr (t % NW == W) {
-      float* w = win + I * 16 * 17;
+    float* w = win + I * 16 * 17;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) w[(4 * g + r) * 17 + c] = acc[t / NW][r];
-    }
+    for (int r = 0; r < 4; ++r) w[(4 * g + r) * 17 + c] = acc[t][r];
   });
   static_for<NB>([&](auto ic) {
     constexpr int I = decltype(ic)::value;
     constexpr int t = tile_of<NB>(I, I);
-    if constexpr (t % NW == W) {
-      const float* w = win + I * 16 * 17;
+    const float* w = win + I * 16 * 17;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[t / NW][r] = 0.5f * (acc[t / NW][r] + w[c * 17 + 4 * g + r]);
-    }
+    for (int r = 0; r < 4; ++r) acc[t][r] = 0.5f * (acc[t][r] + w[c * 17 + 4 * g + r]);
   });
 }
 
@@ -525,7 +499,7 @@ __device__ __forceinline__ void stage_step(const WaveGather<NB>& wg, Planes<NB, 
   }
   static_for<4 * NB>([&](auto uc) { split_pair<NB, decltype(uc)::value / 4, decltype(uc)::value % 4>(R, P); });
   if constexpr (ARITH == kArithSplit3) {
-    u32x4 h2 = {0u, 0u, 0u, 0u};
+    u32x4 h2[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
     static_for<GramSched<NB>::N>([&](auto nc) { gram_mfma_sched<NB, decltype(nc)::value>(P, acc, h2); });
   } else {
     static_for<gram_products<ARITH>()>([&](auto pc) { gram_product<NB, decltype(pc)::value>(P, acc); });
@@ -707,183 +681,6 @@ __device__ __forceinline__ void wave_sse_add(double* bins, double sse, int rowle
 // p0 .. p0 + 3 (block row Ip, lane group q); rounds 2-3 ran every panel's rank-4 update on all live tiles with fp32 MFMAs
 // (lu_wave, and a software-pipelined form of it: profiles/r04/lu_wave_serial_and_pipelined.hip.txt).
 // ----------------------------------------------------------------------------------
-struct LuLane {  // loop-invariant lane constants
-  int c, kk;
-  bool k1, k2, k3;
-  float e1c, e2c, e3c;
-};
-template <int NB, int Ip>
-__host__ __device__ constexpr int lu_prep_steps() { return 2 * (NB - Ip) + 8; }
-
-// ----------------------------------------------------------------------------------
-// The elimination BLOCKED by block rows (round 4: lu_wave_blocked, the LU the wave kernels run).  Measured on this part
-// (tools/probes/issue_probe3.hip, profiles/r04/issue_probe3.txt): v_mfma_f32_16x16x4_f32 takes 36 cycles and does NOT run beside
-// VALU work -- neither of its own wave nor of the partner wave (8 MFMAs + 48 v_fma: 611 cycles against 293 + 379) -- so the
-// 333 rank-4 updates of the panel-serial form (12 k cycles) simply add to its ~2 200 VALU instructions (10 k): 21.5 k cycles
-// per system, which is what the Theta side showed, and why interleaving them inside the wave bought 1 %.  The bf16 MFMA is
-// different: 20 cycles for K = 16 or 32 and VALU work runs in its shadow (8 MFMAs + 48 v_fma: 335 cycles against 166 + 362).
-// So only what the NEXT panel of the same block row needs stays on the fp32 pipe, and everything below the block row waits
-// for the block row to finish:
-//   per panel (four pivots)  eliminated rows u_k as before, scaled to w_k = u_k / sqrt(u_kk) (v_rsq_f32), and ONE rank-4
-//                            fp32 MFMA per tile of the block row itself: 109 of them instead of 333;
-//   per block row            the four w of every feature block below it, split exactly into three bf16 terms (the split
-//                            of the Gram pass), and the rank-16 update of every tile below the block row as six
-//                            v_mfma_f32_16x16x16_bf16 (hh, hm, mh, mm, hl, lh: 24-bit products, fp32 accumulation).  K slot
-//                            (lane group g, element e) = pivot 4 e + g of the block row: exactly where w of panel e sits,
-//                            no data movement.  Both operands are the same w: the accumulators hold -A (negated once, with
-//                            the diagonal term) so that the update is the positive product w_k[i] w_k[j].
-// Cholesky-like scaling, LU-like pivots: u_kk > 0 for the positive definite systems of ALS; an all-zero system gives NaN as
-// the reference's unpivoted LU does.  Parity is by tolerance (the order of operations is not that of the right-looking loop the test restatement runs).
-// What it bought (profiles/r04/lu_parts.txt, lu_three_way_ab.txt): the solve alone 4.55 -> 4.25 ms per Netflix Theta pass
-// (480 189 systems), Theta side at f = 64 6.30 -> 5.87 ms, at f = 100 10.9 -> 10.8 ms (inside the box-to-box noise): a fused
-// half-iteration costs the SUM of its Gram pass and its solve -- both phases are bound by VALU-type issue slots (an MFMA is
-// one), so a wave in its Gram phase and its SIMD partner in the LU do not hide each other.
-// ----------------------------------------------------------------------------------
-template <int NB>
-struct LuPrepS {  // state of one panel's preparation
-  float R[NB][4];  // raw panel rows of -A at this lane's columns (ds_bpermute from lane group q)
-  float n0, n1, n2, n3;      // this lane's column of the panel's four rows of the diagonal tile (the pivot block in the quad 4 q .. 4 q + 3)
-  float rs0, rs1, rs2, rs3;  // 1 / sqrt(u_kk), quad-uniform
-  float t0, t1, t2;          // multipliers: quad lane i holds m_i0, m_i1, m_i2
-  float e0, e1, e2, rsk;     // row kk of E and 1 / sqrt(u_kk) of this lane group's pivot (after the broadcast)
-};
-struct LuLaneS : LuLane {
-  bool j1, j2, j3, j0;  // position in the quad: (c & 3) >= 1, >= 2, == 3, == 0
-  float d1, d2;         // unit diagonal of E seen from the quad: (c & 3) == 1, == 2
-};
-
-// value of quad lane I in all four lanes of every quad (DPP quad_perm [I, I, I, I])
-template <int I>
-__device__ __forceinline__ float quad_bcast(float v) {
-  // bound_ctrl set: lets the compiler fold the move into the consuming VOP1 / VOP2 instruction (v_rsq_f32_dpp, v_fmac_f32_dpp)
-  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), I * 0x55, 0xf, 0xf, true));
-}
-
-// acc + (quad lane I of t) * n as ONE v_fmac_f32_dpp (the compiler's DPP combiner leaves the tied-operand fmac alone and emits
-// v_mov_b32_dpp + v_fmac).  Inline asm is opaque to the hazard recogniser, so the two wait states a DPP read needs behind a
-// VALU write of the same register are spelled out (s_nop 1).
-template <int I>
-__device__ __forceinline__ float fma_quad_bcast(float t, float n, float acc) {
-  static_assert(I >= 0 && I < 4, "quad lane");
-  if constexpr (I == 0) asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(t), "v"(n));
-  if constexpr (I == 1) asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(t), "v"(n));
-  if constexpr (I == 2) asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(t), "v"(n));
-  if constexpr (I == 3) asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(t), "v"(n));
-  return acc;
-}
-
-// Micro-step STEP of the preparation of panel (Ip, q) on the negated system N = -A; w[b]: w of this panel at block b, wm:
-// w[Ip] masked to the rows below the pivot (the A operand of the block row's own update).
-// Round 4: the 4 x 4 pivot block is eliminated WHERE IT IS -- quad lanes 4 q .. 4 q + 3 of lane group q hold its columns in
-// registers 0..3 of the diagonal tile -- by every lane on its own column with DPP quad broadcasts: N_ij += (N_0i / u_00) N_0j
-// etc.  No v_readlane (10 + 7 v_mov per panel), no wave-uniform scalar chain; the rows of E and 1 / sqrt(u_kk) come out in
-// quad lane kk and reach lane group kk with four ds_bpermute.  ~30 VALU per panel instead of ~66.
-template <int NB, int Ip, int q, bool DYN, int STEP>
-__device__ __forceinline__ void lu_prep_step_s(const f32x4 (&acc)[NB * (NB + 1) / 2], LuPrepS<NB>& s, float (&w)[NB], float& wm,
-                                               float* rdiag, int f, const LuLaneS& ln, int dbg = 0) {
-  constexpr int L = NB - Ip;
-  constexpr int SD = tile_of<NB>(Ip, Ip);
-  constexpr int p0 = 16 * Ip + 4 * q;
-  auto sel = [](bool p, float a, float b) { return p ? a : b; };
-  auto rsq = [](float d) { return __builtin_amdgcn_rsqf(d); };
-  auto bperm = [](int addr, float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
-  };
-  const bool v1 = !DYN || p0 + 1 < f, v2 = !DYN || p0 + 2 < f, v3 = !DYN || p0 + 3 < f;
-  if constexpr (STEP == 0) {
-    s.n0 = acc[SD][0], s.n1 = acc[SD][1], s.n2 = acc[SD][2], s.n3 = acc[SD][3];
-    s.rs0 = rsq(-quad_bcast<0>(s.n0));
-    s.t0 = s.n0 * (s.rs0 * s.rs0);  // quad lane i: m_i0 = N_0i / u_00
-    s.n1 = fma_quad_bcast<1>(s.t0, s.n0, s.n1);
-    s.n2 = fma_quad_bcast<2>(s.t0, s.n0, s.n2);
-    s.n3 = fma_quad_bcast<3>(s.t0, s.n0, s.n3);
-  } else if constexpr (STEP <= L) {
-    constexpr int b = Ip + STEP - 1;
-    constexpr int t = tile_of<NB>(Ip, b);
-    const int src = 4 * (16 * q + ln.c);  // byte address of lane (q, c)
-    // (the element goes through a float first: __builtin_bit_cast applied to a vector-element lvalue reads element 0)
-#if CUMF_ABLATE
-    // profiling build: 4096 / 8192 = the panel rows of the blocks right of the diagonal tile without their broadcast
-    if ((dbg & (4096 | 8192)) && b > Ip) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) s.R[b][r] = acc[t][r];
-    } else
-#endif
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float v = acc[t][r];
-      s.R[b][r] = bperm(src, v);
-    }
-  } else if constexpr (STEP == L + 1) {
-    const float d = -quad_bcast<1>(s.n1);
-    s.rs1 = rsq(DYN ? sel(v1, d, 1.0f) : d);
-    s.t1 = s.n1 * (s.rs1 * s.rs1);
-    s.n2 = fma_quad_bcast<2>(s.t1, s.n1, s.n2);
-    s.n3 = fma_quad_bcast<3>(s.t1, s.n1, s.n3);
-  } else if constexpr (STEP == L + 2) {
-    const float d = -quad_bcast<2>(s.n2);
-    s.rs2 = rsq(DYN ? sel(v2, d, 1.0f) : d);
-    s.t2 = s.n2 * (s.rs2 * s.rs2);
-    s.n3 = fma_quad_bcast<3>(s.t2, s.n2, s.n3);
-  } else if constexpr (STEP == L + 3) {
-    const float d = -quad_bcast<3>(s.n3);
-    s.rs3 = rsq(DYN ? sel(v3, d, 1.0f) : d);
-    // multipliers that exist: m_i0 for i >= 1, m_i1 for i >= 2, m_32
-    s.t0 = sel(ln.j1, s.t0, 0.f);
-    s.t1 = sel(ln.j2, s.t1, 0.f);
-    s.t2 = sel(ln.j3, s.t2, 0.f);
-  } else if constexpr (STEP == L + 4) {
-    // rows of E = (unit lower triangle of the panel)^-1 in the quad: lane kk holds E[kk][0..2]
-    const float a = fma_quad_bcast<1>(s.t0, s.t1, s.t0);           // lane 1: m10, lane 2: e20, lane 3: m31 m10 + m30
-    s.e0 = sel(ln.j0, 1.0f, fma_quad_bcast<2>(a, s.t2, a));          // lane 3: m32 e20 + m31 m10 + m30 = e30
-    s.e1 = fma_quad_bcast<2>(s.t1, s.t2, s.t1) + ln.d1;              // lane 1: 1, lane 2: m21, lane 3: m32 m21 + m31 = e31
-  } else if constexpr (STEP == L + 5) {
-    s.e2 = s.t2 + ln.d2;                                              // lane 2: 1, lane 3: m32
-    float rsk = sel(ln.j3, s.rs3, sel(ln.j2, s.rs2, sel(ln.j1, s.rs1, s.rs0)));
-    if constexpr (DYN) rsk = sel(p0 + (ln.c & 3) < f, rsk, 0.f);  // a pivot past f (short last panel) eliminates nothing
-    s.rsk = rsk;
-  } else if constexpr (STEP == L + 6) {
-    // quad lane kk of lane group q -> every lane of lane group kk
-    const int src = 4 * (20 * q + ln.kk);
-    s.e0 = bperm(src, s.e0);
-    s.e1 = bperm(src, s.e1);
-    s.e2 = bperm(src, s.e2);
-    s.rsk = bperm(src, s.rsk);
-  } else if constexpr (STEP == L + 7) {
-    // the back substitution runs on the rows of -U that stay in the accumulators: it wants 1 / (-u_kk) (all 16 lanes of
-    // a group write the same value to the same word; p0 + kk < (f + 3) & ~3 always, a pivot past f is never read)
-    rdiag[p0 + ln.kk] = -(s.rsk * s.rsk);
-  } else {
-    constexpr int b = Ip + STEP - (L + 8);
-#if CUMF_ABLATE
-    // profiling build: 8192 = the eliminated rows of the blocks right of the diagonal tile by ONE fp32 MFMA on the
-    // accumulator registers (what a stride-4 pivot order would issue; wrong values here)
-    if ((dbg & 8192) && b > Ip) {
-      const f32x4 z = __builtin_amdgcn_mfma_f32_16x16x4f32(s.e0 * s.rsk, acc[tile_of<NB>(Ip, b)][q], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-      w[b] = z[0];
-      return;
-    }
-#endif
-    const float un = fmaf(ln.e3c, s.R[b][3], fmaf(s.e2, s.R[b][2], fmaf(s.e1, s.R[b][1], s.e0 * s.R[b][0])));  // -u_k at block b
-    w[b] = un * s.rsk;  // the sign is immaterial: w meets itself
-    if constexpr (b == Ip) wm = sel(ln.c > 4 * q + ln.kk, w[b], 0.f);  // rows at or above the pivot stay
-  }
-}
-
-// exact three-way split of (a, b) into packed bf16 pairs (a in the low half), as split_micro does for the gathered rows
-__device__ __forceinline__ void split3_pair(float a, float b, unsigned& H, unsigned& M, unsigned& Lw) {
-  H = pack_bf16(a, b);
-  const float ra = sub_bf16_lo(a, H), rb = sub_bf16_hi(b, H);
-  M = pack_bf16(ra, rb);
-  const float ta = sub_bf16_lo(ra, M), tb = sub_bf16_hi(rb, M);
-  Lw = pack_bf16(ta, tb);
-}
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x4 mfma_bf16_k16(u32x2 a, u32x2 b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(bf16x4, a), __builtin_bit_cast(bf16x4, b), c, 0, 0, 0);
-}
-
 // n-th tile (row-major) of the part of the upper triangle below block row I0: rows I0 .. NB - 1
 template <int NB, int I0>
 __host__ __device__ constexpr int lu_trailing_tile(int n) {
@@ -1536,13 +1333,10 @@ __device__ __forceinline__ void multi_body(float* smem, const KernelArgs& a, lon
               if constexpr (PROD == 0) acc[sl] = mfma_f16(P.l[I], P.h[J], acc[sl]);
               if constexpr (PROD == 1) acc[sl] = mfma_f16(P.h[I], P.l[J], acc[sl]);
               if constexpr (PROD == 2) acc[sl] = mfma_f16(P.h[I], P.h[J], acc[sl]);
-            } else if constexpr (I == J) {
-              // diagonal tile: D + 2 S in four products (see make_gram_sched), restored behind the last stage
-              if constexpr (PROD == 1) acc[sl] = mfma_bf16(bf16x8_times2(P.h[I]), P.l[I], acc[sl]);
-              if constexpr (PROD == 2) acc[sl] = mfma_bf16(P.m[I], P.m[I], acc[sl]);
-              if constexpr (PROD == 4) acc[sl] = mfma_bf16(bf16x8_times2(P.h[I]), P.m[I], acc[sl]);
-              if constexpr (PROD == 5) acc[sl] = mfma_bf16(P.h[I], P.h[I], acc[sl]);
             } else {
+              // (the four-product form of the diagonal tiles -- make_gram_sched -- was measured here too, round 5: 13 of 91
+              // tiles, the doubled plane recomputed per product, one more barrier per item: f = 200 X side 29.73 vs 29.75 ms,
+              // Theta side CG 36.0 vs 35.6, f = 128 LU 26.9 vs 26.9 -- no gain with one wave per SIMD, not kept)
               if constexpr (PROD == 0) acc[sl] = mfma_bf16(P.l[I], P.h[J], acc[sl]);
               if constexpr (PROD == 1) acc[sl] = mfma_bf16(P.h[I], P.l[J], acc[sl]);
               if constexpr (PROD == 2) acc[sl] = mfma_bf16(P.m[I], P.m[J], acc[sl]);
@@ -1556,10 +1350,6 @@ __device__ __forceinline__ void multi_body(float* smem, const KernelArgs& a, lon
     }
   }
   if constexpr (ARITH == kArithFast) fast_unscale<NB, NW, W>(acc, a.fast_flag);
-  if constexpr (ARITH == kArithSplit3) {
-    __syncthreads();  // the partner is done with the last stage's chunks: the transposition windows alias the stage buffers
-    wave_symmetrise_diag<NB, NW, W>(acc, smem, lane);
-  }
   // a whole row (no slot): the two waves solve it where the tiles are -- 93 KB per row at f = 200 that
   // neither go out to HBM nor come back (measured: 45 GB each way per Netflix X half-iteration)
   if (slot < 0) {

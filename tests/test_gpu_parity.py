@@ -865,7 +865,12 @@ def test_doals_fused_rmse_near_perfect_fit_is_reevaluated(alslib):
     from cumf_als_amd import als, datagen
 
     m, n, nnz, nnz_test, f, lam = 600, 500, 60000, 2000, 16, 1e-7
-    r = datagen.synth_ratings(m, n, nnz, nnz_test, seed=3, rank=4, noise=0.0)
+    rng = np.random.RandomState(3)
+    cells = rng.choice(m * n, nnz + nnz_test, replace=False)
+    rows, cols = cells // n, cells % n
+    xs, ts = rng.uniform(0.5, 1.5, (m, 4)), rng.uniform(0.5, 1.5, (n, 4))
+    vals = (xs[rows] * ts[cols]).sum(1).astype(np.float32)          # exactly rank 4, no noise, not quantised
+    r = datagen.from_coo(m, n, rows[:nnz], cols[:nnz], vals[:nnz], rows[nnz:], cols[nnz:], vals[nnz:])
     d = r.numpy()
     th0 = _factors(n, f, 2)
 
