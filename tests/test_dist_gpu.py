@@ -163,6 +163,44 @@ def test_rccl_backend_world1(oracle, alslib, scheme, solver):
     assert np.abs(x - x_ref).max() <= tol * np.abs(x_ref).max()
 
 
+def test_bench_hugewiki_leg_over_rccl_world1(alslib):
+    """The hugewiki leg of the N > 1 bench line over the backend the driver's 8-GPU run uses: RCCL
+    ("nccl"), device tensors in every collective of the leg (MAX all-reduce of the elapsed time, all-gather of the per-rank
+    diagnostics, the reduce-scatter / all-gather of the `reduce` scheme).  One rank is all a 1-GPU box allows; the two-rank
+    form of the same code runs over gloo in test_bench_world2_branch_runs."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from tests.test_dist_cpu import _free_port
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import argparse, json, os, sys, torch\n"
+        "import torch.distributed as dist\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "import bench\n"
+        "from cumf_als_amd import als, datagen\n"
+        "torch.cuda.set_device(0)\n"
+        "dev = torch.device('cuda', 0)\n"
+        "dist.init_process_group('nccl', device_id=dev)\n"
+        "a = argparse.Namespace(scale=0.05, seed=0, theta_batch=0, reference_solvers=False)\n"
+        "out = bench.hugewiki_leg(a, als, datagen, dev, 1, 0, 'nccl', steps=2)\n"
+        "print(json.dumps(out))\n"
+        "dist.destroy_process_group()\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    hw = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert hw["scaling"] == "weak" and hw["scheme"] == "reduce" and hw["n_ranks_seen"] == 1
+    assert hw["value"] > 0 and np.isfinite(hw["value"]) and hw["x_half_ms"] > 0 and hw["theta_half_ms"] > 0
+
+
 def test_pack_unpack_upper(alslib):
     """cumf_pack_upper / cumf_unpack_upper: the packed upper triangle that the multi-GPU Theta phase
     reduce-scatters (half the bytes of hugewiki.cu:2703-2717's full f x f copies)."""
