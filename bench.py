@@ -679,6 +679,9 @@ def main() -> int:
         # fp32 MFMA path
         products = (3 if mode == "fast" else 6) if wave else 1
         issued = nb * (nb + 1) / 2 * 512.0 * products
+        if wave and mode == "auto" and nb <= 7:
+            # round 5: the diagonal tiles of the one-wave kernels take four products (D + 2 S, restored per item): 2 nb fewer MFMAs
+            issued -= 2 * nb * 512.0
         pipe_peak = 2500.0 if wave else MFMA_F32_PEAK_TFLOPS
         nnz_gpu = r.nnz
 
