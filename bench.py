@@ -721,7 +721,8 @@ def main() -> int:
             "gram_tflops": float(nnz_gpu) * f * (f + 1) / (avg_ms * 1e-3) / 1e12,
             # the matrix pipe next to the HBM roof: flops issued (tile padding and, on the split path,
             # the six bf16 products per fp32 product included) against the pipe's dense peak
-            "mfma": {"bound": "mfma", "pipe": (f"{'f16' if mode == 'fast' else 'bf16'} ({products} products per fp32 product)"
+            "mfma": {"bound": "mfma", "pipe": (f"{'f16' if mode == 'fast' else 'bf16'} ({products} products per fp32 product"
+                                                + ("; 4 on the diagonal tiles)" if mode == "auto" and nb <= 7 else ")")
                                                 if wave else "fp32"),
                      "achieved": float(nnz_gpu) * issued / (avg_ms * 1e-3) / 1e12, "peak": pipe_peak, "unit": "TFLOP/s",
                      "frac": float(nnz_gpu) * issued / (avg_ms * 1e-3) / 1e12 / pipe_peak},
