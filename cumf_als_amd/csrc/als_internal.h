@@ -21,10 +21,9 @@ constexpr int kVecLd = 128;     // pitch of the CG vectors in LDS (fused solve n
 constexpr int kMaxFusedNB = 9;  // f <= 128  ->  NB = f / 16 + 1 <= 9
 constexpr int kMaxF = 207;      // NB <= 13
 constexpr int kMaxWaveNB = 7;   // wave-per-item kernels (als_wave.hip): f <= 111; register budget of one wave
-#ifndef CUMF_MAX_FUSED_LU_NB
-#define CUMF_MAX_FUSED_LU_NB 9
-#endif
-constexpr int kMaxFusedLuWaveNB = CUMF_MAX_FUSED_LU_NB;  // two-wave kernel: LU in place up to this NB (CG: always)
+// two-wave kernel: LU in place up to this NB (CG: always).  Round 5 measured 13 (f = 200 solved in place by the two Gram
+// waves): Theta side 82.4 vs 74.4 ms through the tile buffer (profiles/r05/lu_rows_ab.txt)
+constexpr int kMaxFusedLuWaveNB = 9;
 
 enum { kModeCG = 0, kModeLU = 1, kModeMaterialize = 2, kModeLUExact = 3, kModeCGHalf = 4 };  // CGHalf: A stored as fp16
 
