@@ -348,6 +348,35 @@ def get_gram_mode() -> str:
     return {GRAM_EXACT: "exact", GRAM_FAST: "fast"}.get(_libmod.load().cumf_get_gram_mode(), "auto")
 
 
+PRESPLIT_AUTO, PRESPLIT_OFF, PRESPLIT_ON = -1, 0, 1
+
+
+def set_presplit(mode) -> None:
+    """Pre-split gather tables (cumf_set_presplit): "auto" = where the planes of the table stay in the caches (default),
+    "off" / "on" = never / whenever the shape allows.  Results are bit-identical either way."""
+    m = {"auto": PRESPLIT_AUTO, "off": PRESPLIT_OFF, "on": PRESPLIT_ON}.get(mode, mode)
+    _libmod.check(_libmod.load().cumf_set_presplit(int(m)), "cumf_set_presplit")
+
+
+def get_presplit() -> str:
+    return {PRESPLIT_OFF: "off", PRESPLIT_ON: "on"}.get(_libmod.load().cumf_get_presplit(), "auto")
+
+
+def presplit_table(table: "torch.Tensor") -> "torch.Tensor":
+    """The bf16 h | m | l planes of a rows x f fp32 table as the fused calls build them (cumf_presplit_table): a uint8
+    tensor [rows, cumf_presplit_pitch(f)]."""
+    import torch
+
+    lib = _libmod.load()
+    rows, f = int(table.shape[0]), int(table.shape[1])
+    pitch = int(lib.cumf_presplit_pitch(f))
+    if pitch == 0:
+        raise ValueError(f"no pre-split kernels for f = {f}")
+    out = torch.empty((rows, pitch), dtype=torch.uint8, device=table.device)
+    _libmod.check(lib.cumf_presplit_table(_dp(table, torch.float32), out.data_ptr(), rows, f, _stream()), "cumf_presplit_table")
+    return out
+
+
 def gram_fast_status() -> int:
     """Range report of gram mode "fast" since the last call (waits for the device; cumf_gram_fast_status):
     bit 0 = a factor, bit 1 = a rating beyond the f16 range; 0 = clean."""

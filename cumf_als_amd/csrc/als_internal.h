@@ -90,6 +90,10 @@ struct KernelArgs {
   // (presplit_f16x2_kernel) and range violations are OR-ed into *fast_flag (bit 0: table, bit 1: ratings)
   int fast_words;
   int* fast_flag;
+  // round 6 (kArithPre): `gather` points at the pre-split bf16 h | m | l planes of the factor table (presplit_bf16x3_kernel),
+  // rows of pre_pitch bytes
+  int pre_words;
+  unsigned pre_pitch;
   // fused train SSE (als.cu:979-991 folded into the Theta update): when not null, every whole-row item of a wave-kernel
   // launch adds sum_u (r_uv - x_u . theta_v)^2 of its row to sse_bins[item % kSseBins] (fp64 atomics)
   double* sse_bins;
@@ -132,6 +136,13 @@ bool wave_batched_path(int f, int mode);
 // unpack = 0: full (batch x f x f) -> packed (batch x f(f+1)/2); unpack = 1: `full` is the packed input,
 // `packed` receives the mirrored full matrices
 hipError_t launch_presplit(const float* src, unsigned* dst, size_t n, int* flag, hipStream_t stream);
+// kArithPre: which (f, NB) have kernels on the pre-split bf16x3 table (als_wave.hip: CUMF_WAVE_PRE, presplit_shape_ok), the
+// table's row pitch in bytes, and the kernel that writes it
+__host__ __device__ constexpr bool presplit_supported(int f) {
+  return (nb_for_f(f) == 7 || nb_for_f(f) == 5) && ((f & 15) == 0 || (f & 15) == 4);
+}
+__host__ __device__ constexpr unsigned presplit_pitch(int f) { return 96u * (f / 16) + (((f & 15) >> 2) ? 32u : 0u); }
+hipError_t launch_presplit3(const float* src, void* dst, long long rows, int f, hipStream_t stream);
 hipError_t launch_pack_upper(const float* full, float* packed, long batch, int f, int unpack, hipStream_t stream);
 void set_last_error(int code);  // read (and cleared) by cumf_last_error
 void set_kernel_timing(bool on);

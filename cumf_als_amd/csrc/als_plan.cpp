@@ -288,7 +288,7 @@ namespace {
 // copy of the gather table (gram mode "fast").  Process-wide, grow-only, one buffer per (device, stream, kind):
 // calls on one stream are ordered, so the X_BATCH / THETA_BATCH plans of doALS and the pipeline pieces of
 // DistALS share ONE buffer instead of keeping one each.  cumf_release_scratch frees them.
-enum { kScratchTiles = 0, kScratchWords = 1 };
+enum { kScratchTiles = 0, kScratchWords = 1, kScratchPlanes = 2 };
 struct Scratch {
   void* ptr = nullptr;
   size_t cap = 0;
@@ -446,6 +446,39 @@ int fast_words(const cumf_plan_t* p, const float* gather, int f, hipStream_t str
   return 0;
 }
 
+// Round 6 (kArithPre, als_wave.hip): a gather table that lives in the caches -- the Netflix Theta side gathers X (7 MB), the
+// hugewiki X side Theta (16 MB) -- is rewritten per call as bf16 h | m | l planes (1.5 x the bytes, the SAME bits the in-kernel
+// split produces) and the Gram stage takes its MFMA operands from it with 16-byte LDS-DMA + transposing LDS reads instead of
+// ~250 VALU instructions of split per 32 ratings.  An HBM-resident table (the Netflix X side gathers 192 MB of Theta) stays
+// fp32: there the bytes are the roof.  CUMF_ALS_PRESPLIT = 0 never / 1 whenever the shape allows / unset: tables whose
+// planes take at most CUMF_ALS_PRESPLIT_MB (default 64) MB.
+int g_presplit_mode = -2;  // -2: not read yet; CUMF_PRESPLIT_*
+int presplit_mode() {
+  if (g_presplit_mode == -2) {
+    const char* env = getenv("CUMF_ALS_PRESPLIT");
+    g_presplit_mode = (env && env[0] == '0') ? CUMF_PRESPLIT_OFF : (env && env[0] == '1') ? CUMF_PRESPLIT_ON : CUMF_PRESPLIT_AUTO;
+  }
+  return g_presplit_mode;
+}
+bool presplit_wanted(const cumf_plan_t* p, int f, int mode) {
+  static const double cap_mb = getenv("CUMF_ALS_PRESPLIT_MB") ? atof(getenv("CUMF_ALS_PRESPLIT_MB")) : 64.0;
+  const int pm = presplit_mode();
+  if (pm == CUMF_PRESPLIT_OFF) return false;
+  if (gram_mode() != kGramAuto || !wave_path_available(f, mode) || !presplit_supported(f) || p->gather_rows <= 0) return false;
+  if (pm == CUMF_PRESPLIT_ON) return true;
+  return (double)p->gather_rows * presplit_pitch(f) <= cap_mb * 1048576.0;
+}
+int pre_words(const cumf_plan_t* p, const float* gather, int f, hipStream_t stream, KernelArgs* a) {
+  void* planes = nullptr;
+  const int rc = scratch_get(stream, kScratchPlanes, (size_t)p->gather_rows * presplit_pitch(f), &planes);
+  if (rc) return rc;
+  CUMF_HIP_CHECK(launch_presplit3(gather, planes, p->gather_rows, f, stream));
+  a->gather = reinterpret_cast<const float*>(planes);
+  a->pre_words = 1;
+  a->pre_pitch = presplit_pitch(f);
+  return 0;
+}
+
 thread_local int g_last_error = 0;  // per host thread: concurrent doALS calls do not see each other's state
 
 }  // namespace
@@ -578,6 +611,9 @@ int update_fused_impl(const cumf_plan_t* p, const int* colidx, const float* val,
   }
   if (gram_mode() == kGramFast && (batched || wave_path_available(f, mode))) {
     const int rc = fast_words(p, gather, f, static_cast<hipStream_t>(stream), &a);
+    if (rc) return rc;
+  } else if (presplit_wanted(p, f, mode)) {
+    const int rc = pre_words(p, gather, f, static_cast<hipStream_t>(stream), &a);
     if (rc) return rc;
   }
   CUMF_HIP_CHECK(launch_half_iteration(a, mode, p->n_items, p->n_mrows, static_cast<hipStream_t>(stream), &lists));
@@ -749,6 +785,19 @@ extern "C" int cumf_set_gram_mode(int mode) {
   return 0;
 }
 extern "C" int cumf_get_gram_mode(void) { return gram_mode(); }
+
+extern "C" int cumf_set_presplit(int mode) {
+  if (mode != CUMF_PRESPLIT_AUTO && mode != CUMF_PRESPLIT_OFF && mode != CUMF_PRESPLIT_ON) return (int)hipErrorInvalidValue;
+  g_presplit_mode = mode;
+  return 0;
+}
+extern "C" int cumf_get_presplit(void) { return presplit_mode(); }
+extern "C" long cumf_presplit_pitch(int f) { return presplit_supported(f) ? (long)presplit_pitch(f) : 0; }
+extern "C" int cumf_presplit_table(const float* table, void* planes, long rows, int f, void* stream) {
+  if (!table || !planes || rows < 0 || !presplit_supported(f)) return (int)hipErrorInvalidValue;
+  CUMF_HIP_CHECK(launch_presplit3(table, planes, rows, f, static_cast<hipStream_t>(stream)));
+  return 0;
+}
 
 #if CUMF_ABLATE
 // profiling build only (not declared in include/): see debug_switches() above

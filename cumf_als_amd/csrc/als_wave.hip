@@ -59,12 +59,15 @@ typedef __attribute__((address_space(3))) float* lds_float_ptr;  // LDS pointer 
 #error "compile with -DCUMF_WAVE_NB=<feature blocks>"
 #endif
 
+// feature-block counts whose kernels also exist on the pre-split table (kArithPre): f = 96 .. 111 and f = 64 .. 79 -- the
+// headline f = 100 and BASELINE configs[4]'s f = 64 (presplit_nb_ok in als_internal.h is the host's copy of this list)
+#define CUMF_WAVE_PRE (CUMF_WAVE_NB == 7 || CUMF_WAVE_NB == 5)
 constexpr int kWaveStage = 32;   // ratings per stage = K of v_mfma_f32_16x16x32_bf16
 constexpr int kZeroFloats = 256; // >= 16 * kMaxWaveNB + 16
 
 // Zeros that stand in for "no rating here": ratings past the end of an item gather from
 // this row, the pad lanes of the last feature block read it too.
-static __device__ float g_wave_zeros[kZeroFloats];
+static __device__ __attribute__((aligned(16))) float g_wave_zeros[kZeroFloats];
 
 __device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
@@ -79,7 +82,13 @@ __device__ __forceinline__ f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 c) {
 // kArithFast: the gather table arrives PRE-SPLIT (presplit_f16x2_kernel, als_kernels.hip): one 32-bit word
 // per value = (h, l) f16 pair of 4096 x, x ~ (h + l) / 4096 to 2^-22; three f16 products hh + hl + lh
 // (the dropped ll is < 2^-22 of the product), fp32 accumulation, accumulators scaled back by 2^-24.
-enum { kArithSplit3 = 0, kArithFast = 1 };
+// kArithPre (round 6): the 24-bit arithmetic of kArithSplit3 -- the same three bf16 planes, the same products, the same
+// K slots, bit-identical accumulators -- from a gather table that arrives PRE-SPLIT (presplit_bf16x3_kernel: per row the
+// h | m | l planes as 16-bit arrays): the rows are copied into LDS by 16-byte LDS-DMA and the MFMA operands come out of
+// ds_read_b64_tr_b16, the 16-bit transposing read of gfx950 -- no split, no pack, no select on the VALU.  For gather
+// tables that live in the caches (the Netflix Theta side: X = 7 MB; the hugewiki X side: Theta = 16 MB); an HBM-resident
+// table stays fp32 (1.5 x the bytes would cost more than the VALU work saves).
+enum { kArithSplit3 = 0, kArithFast = 1, kArithPre = 2 };
 constexpr float kFastScale = 4096.0f;             // values must stay below 65504 / 4096 = 15.99 in magnitude
 constexpr float kFastUnscale = 1.0f / (4096.0f * 4096.0f);
 
@@ -507,6 +516,214 @@ __device__ __forceinline__ void stage_step(const WaveGather<NB>& wg, Planes<NB, 
 }
 
 // ----------------------------------------------------------------------------------
+// kArithPre: the stage on a pre-split gather table (round 6; tools/probes/tr16_dma_probe.hip pins the two instructions).
+//
+// Table row (presplit_bf16x3_kernel), FB = f / 16 full feature blocks, SP = (f % 16) / 4 in {0, 1} strip pieces:
+//   [h: 16 FB bf16][m: 16 FB bf16][l: 16 FB bf16] [strip, if SP: h, m, l of features 16 FB .. 16 FB + 3 (8 B each) + 8 B of zeros]
+// LDS image of a 32-rating stage:
+//   main    chunk (E, p), E = 0..7, p = plane: the plane of FOUR ratings rho = 4 E + q, q = 0..3, at RP bytes each, written
+//           by ONE global_load_lds_dwordx4 (lane l = LP q + piece: 16 bytes -> chunk + 16 l; the lanes behind the 2 FB pieces
+//           of a rating are masked off); 24 chunks instead of 56 dword gathers.  RP = 192 (64 for FB <= 2) and a 32-byte
+//           skew per E pair put the eight 32-byte row pieces a transposing read touches per half wave into eight bank groups.
+//   strip   [rho][h 8 B | m 8 B | l 8 B | 0] of the 32 ratings: one more 16-byte LDS-DMA (lane l: rating l / 2, half l % 2)
+//   rating  [rho][r_h 0 0 0 | r_m 0 0 0 | r_l 0 0 0]: the rating value rides in slot f (als.cu:750-757 fused into the Gram);
+//           it is no table entry, so lane rho splits the value of rating rho of the NEXT stage and stores three halfwords
+//   zeros   24 bytes: what the lanes behind slot f read
+// Operands: ds_read_b64_tr_b16 hands lane 4 a + b of a 16-lane group, as element j, halfword b of the 8-byte piece that lane
+// 4 j + a addresses.  Lane (g, 4 j + a) addresses features 16 B + 4 a .. + 3 of rating rho = 8 g + 4 u + j: lane (g, c) receives
+// feature 16 B + c of the ratings 8 g + 4 u + 0 .. 3 -- K slots 4 u .. 4 u + 3 of the MFMA, exactly the slots the in-kernel
+// split gives them (P.h[B][2 u], [2 u + 1]); same operands in the same slots, same MFMA sequence: the accumulators are
+// bit-identical to kArithSplit3's (tests/test_gpu_parity.py::test_presplit_is_bit_identical).
+// ----------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* lds_tr_ptr;
+template <int NB>
+struct PreGeo {
+  static constexpr int FB = NB - 1;
+  static constexpr int RP = FB <= 2 ? 64 : 192;       // bytes of one rating inside a chunk (>= 32 FB)
+  static constexpr int LP = RP / 16;                  // DMA lanes per rating, 2 FB of them fetch
+  static constexpr int CS = 4 * RP;                   // one chunk: a plane of four ratings
+  static constexpr int kMain = 24 * CS + 3 * 32;      // + the skews: chunk (E, p) at (3 E + p) CS + 32 (E >> 1)
+  static constexpr int kStrip = kMain;                // 32 ratings x 32 B
+  static constexpr int kRating = kStrip + 1024;       // 32 ratings x 24 B
+  static constexpr int kZero = kRating + 768;         // 24 B (32 reserved)
+  static constexpr int kBytes = kZero + 32;
+  static_assert(32 * FB <= RP && 4 * LP <= 64, "a rating's plane fits its slot, four ratings fit the wave");
+  __host__ __device__ static constexpr int chunk(int E, int p) { return (3 * E + p) * CS + 32 * (E >> 1); }
+  // row pitch of the table in bytes (a multiple of 16: the 16-byte LDS-DMA needs aligned sources)
+  __host__ __device__ static constexpr unsigned pitch(int f) { return 96u * FB + (((f & 15) >> 2) ? 32u : 0u); }
+};
+__host__ __device__ constexpr bool presplit_shape_ok(int f) { return (f & 15) == 0 || (f & 15) == 4; }
+
+template <int NB>
+struct PreStage {
+  int idx[8];   // column indices of the ratings 4 E + q of a stage whose main chunks are still to be issued (lanes of DMA group q)
+  int sidx;     // ... of rating lane / 2 (strip)
+  float rv;     // rating value of rating lane & 31
+};
+
+template <int NB>
+struct PreGather {
+  using G = PreGeo<NB>;
+  const char* lane_base;   // table + 16 piece
+  const char* zero_base;   // zero row + 16 piece
+  const char* strip_base;  // table + 96 FB + 16 (lane & 1)
+  const char* strip_zero;
+  const int* ib;           // colidx + begin (the zero row for an item without ratings)
+  const float* vb;         // val + begin (the zero row without ratings / values)
+  lds_tr_ptr tr_main;      // lane part of the addresses of the transposing reads of blocks 0 .. FB - 1
+  lds_tr_ptr tr_last[2];   // ... of the last block, per quad u: strip piece / rating piece / zeros
+  unsigned pitch;
+  int len, q, lane;
+  bool dma_active, sp;
+
+  __device__ __forceinline__ void init(const KernelArgs& a, int f, long long begin, int len_, int lane_, float* smem) {
+    lane = lane_;
+    len = len_;
+    pitch = a.pre_pitch;
+    sp = ((f & 15) >> 2) != 0;
+    q = lane / G::LP;
+    const int piece = lane % G::LP;
+    dma_active = q < 4 && piece < 2 * G::FB;
+    q = q < 4 ? q : 3;
+    lane_base = reinterpret_cast<const char*>(a.gather) + 16 * piece;
+    zero_base = reinterpret_cast<const char*>(g_wave_zeros) + 16 * piece;
+    strip_base = reinterpret_cast<const char*>(a.gather) + 96 * G::FB + 16 * (lane & 1);
+    strip_zero = reinterpret_cast<const char*>(g_wave_zeros) + 16 * (lane & 1);
+    ib = len_ > 0 ? a.colidx + begin : reinterpret_cast<const int*>(g_wave_zeros);
+    vb = (len_ > 0 && a.val != nullptr) ? a.val + begin : g_wave_zeros;
+    const int g = lane >> 4, j = (lane >> 2) & 3, aa = lane & 3;
+    char __attribute__((address_space(3)))* base = (char __attribute__((address_space(3)))*)smem;
+    tr_main = (lds_tr_ptr)(base + 6 * g * G::CS + 32 * g + G::RP * j + 8 * aa);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int rho = 8 * g + 4 * u + j;
+      const int spn = sp ? 1 : 0;
+      const int off = aa < spn ? G::kStrip + 32 * rho + 8 * aa : (aa == spn ? G::kRating + 24 * rho : G::kZero);
+      tr_last[u] = (lds_tr_ptr)(base + off);
+    }
+    // the rating pieces' zero halfwords and the zero pieces, once (LDS operations of one wave execute in order)
+    if (lane < (768 + 32) / 16) reinterpret_cast<f32x4*>(reinterpret_cast<char*>(smem) + G::kRating)[lane] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // indices + rating value of stage s (FULL: every rating of the stage exists)
+  template <bool FULL>
+  __device__ __forceinline__ void load(PreStage<NB>& st, int s) const {
+    const int top = len > 0 ? len - 1 : 0;
+    if constexpr (FULL) {
+      const int* p = ib + kWaveStage * s + q;
+#pragma unroll
+      for (int E = 0; E < 8; ++E) st.idx[E] = p[4 * E];
+      st.sidx = ib[kWaveStage * s + (lane >> 1)];
+      st.rv = vb[kWaveStage * s + (lane & 31)];
+    } else {
+#pragma unroll
+      for (int E = 0; E < 8; ++E) {
+        const int pos = kWaveStage * s + 4 * E + q;
+        st.idx[E] = ib[pos < top ? pos : top];
+      }
+      const int ps = kWaveStage * s + (lane >> 1), pv = kWaveStage * s + (lane & 31);
+      st.sidx = ib[ps < top ? ps : top];
+      const float v = vb[pv < top ? pv : top];
+      st.rv = pv < len ? v : 0.f;  // ratings past the end of the item: zero rows AND a zero rating (sum r^2 of the fused SSE)
+    }
+  }
+
+  // the rating value of stage s (in st.rv) as three bf16 terms into the rating pieces
+  __device__ __forceinline__ void put_rating(const PreStage<NB>& st, float* smem) const {
+    unsigned H, M, L;
+    split3_pair(st.rv, 0.f, H, M, L);
+    if (lane < 32) {
+      unsigned short* rp = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(smem) + G::kRating + 24 * lane);
+      rp[0] = (unsigned short)H;
+      rp[4] = (unsigned short)M;
+      rp[8] = (unsigned short)L;
+    }
+  }
+
+  template <bool FULL>
+  __device__ __forceinline__ void dma_issue(const PreStage<NB>& st, float* smem, int s) const {
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass of hipcc rejects the 16-byte form of the builtin: it checks it against the host target)
+    using gptr = const __attribute__((address_space(1))) void*;
+    using lptr = __attribute__((address_space(3))) void*;
+    char __attribute__((address_space(3)))* lds = (char __attribute__((address_space(3)))*)smem;
+    if (dma_active) {
+      static_for<8>([&](auto ec) {
+        constexpr int E = decltype(ec)::value;
+        const char* row = lane_base + (unsigned long long)(unsigned)st.idx[E] * pitch;  // v_mad_u64_u32
+        if constexpr (!FULL) row = (kWaveStage * s + 4 * E + q < len) ? row : zero_base;
+        static_for<3>([&](auto pc) {
+          constexpr int p = decltype(pc)::value;
+          // the instruction offset (the plane's byte offset in the row) moves BOTH addresses: taken back out of the LDS pointer
+          __builtin_amdgcn_global_load_lds((gptr)row, (lptr)(lds + G::chunk(E, p) - 32 * G::FB * p), 16, 32 * G::FB * p, 0);
+        });
+      });
+    }
+    if (sp) {  // wave-uniform
+      const char* row = strip_base + (unsigned long long)(unsigned)st.sidx * pitch;
+      if constexpr (!FULL) row = (kWaveStage * s + (lane >> 1) < len) ? row : strip_zero;
+      __builtin_amdgcn_global_load_lds((gptr)row, (lptr)(lds + G::kStrip), 16, 0, 0);
+    }
+#endif
+  }
+
+  // the landed stage -> MFMA operands
+  __device__ __forceinline__ void read(Planes<NB>& P) const {
+    auto rd = [](lds_tr_ptr p, int byte_off) {
+      return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                            (lds_tr_ptr)((char __attribute__((address_space(3)))*)p + byte_off)));
+    };
+    static_for<NB>([&](auto bc) {
+      constexpr int B = decltype(bc)::value;
+      static_for<2>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        u32x2 vh, vm, vl;
+        if constexpr (B < G::FB) {
+          vh = rd(tr_main, (3 * u + 0) * G::CS + 32 * B);
+          vm = rd(tr_main, (3 * u + 1) * G::CS + 32 * B);
+          vl = rd(tr_main, (3 * u + 2) * G::CS + 32 * B);
+        } else {
+          vh = rd(tr_last[u], 0);
+          vm = rd(tr_last[u], 8);
+          vl = rd(tr_last[u], 16);
+        }
+        P.h[B][2 * u] = vh[0], P.h[B][2 * u + 1] = vh[1];
+        P.m[B][2 * u] = vm[0], P.m[B][2 * u + 1] = vm[1];
+        P.l[B][2 * u] = vl[0], P.l[B][2 * u + 1] = vl[1];
+      });
+    });
+  }
+};
+
+// One stage: wait for the chunks -> 6 NB transposing reads -> rating pieces + chunks of the next stage, indices + rating of
+// the one after -> MFMAs (the same schedule as kArithSplit3).  R holds what was loaded a step ago: the stage s_next.
+template <int NB, int KIND>
+__device__ __forceinline__ void stage_step_pre(const PreGather<NB>& wg, Planes<NB>& P, PreStage<NB>& R, float* smem,
+                                               f32x4 (&acc)[NB * (NB + 1) / 2], int s_next, int s_load) {
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the chunks of this stage have landed, R is complete
+  wg.read(P);
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the operands are in registers, the image is free
+  if constexpr (KIND == kStepFull) {
+    wg.put_rating(R, smem);
+    wg.template dma_issue<true>(R, smem, s_next);
+    wg.template load<true>(R, s_load);
+  } else if constexpr (KIND == kStepPartial) {
+    const int nfull = wg.len / kWaveStage, nst = (wg.len + kWaveStage - 1) / kWaveStage;
+    wg.put_rating(R, smem);
+    if (s_next < nfull)
+      wg.template dma_issue<true>(R, smem, s_next);
+    else
+      wg.template dma_issue<false>(R, smem, s_next);
+    if (s_load < nfull)
+      wg.template load<true>(R, s_load);
+    else if (s_load < nst)
+      wg.template load<false>(R, s_load);
+  }
+  u32x4 h2[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+  static_for<GramSched<NB>::N>([&](auto nc) { gram_mfma_sched<NB, decltype(nc)::value>(P, acc, h2); });
+}
+
+// ----------------------------------------------------------------------------------
 // Epilogues on the full tile set of one wave (same element layout as als_kernels.hip).
 // ----------------------------------------------------------------------------------
 template <int NB>
@@ -568,8 +785,13 @@ template <int NB>
 __host__ __device__ constexpr int wave_lu_lds_floats(int f) {
   return 16 * NB * kBsPitch + ((f + 3) & ~3) + 16 + 64;  // window + pivot reciprocals + 16 zeros + dummy line
 }
-template <int NB>
-__host__ __device__ constexpr int wave_stage_lds_floats() { return 64 * 8 * NB; }  // 8 NB chunks of 64 floats
+template <int NB, int ARITH = kArithSplit3>
+__host__ __device__ constexpr int wave_stage_lds_floats() {
+  if constexpr (ARITH == kArithPre)
+    return PreGeo<NB>::kBytes / 4;  // the pre-split image of a stage
+  else
+    return 64 * 8 * NB;             // 8 NB chunks of 64 floats
+}
 
 template <int NB, int NQ>
 __device__ __forceinline__ float back_substitute_tiles(const f32x4 (&acc)[NB * (NB + 1) / 2], float* T,
@@ -1183,13 +1405,28 @@ __global__ __launch_bounds__(64, CUMF_WAVE_MIN_WAVES) void als_wave_kernel(const
   if (!(a.dbg & 2))
 #endif
   {
+    auto clamp = [&](int s) { return s < nst ? s : nst - 1; };
+    if constexpr (ARITH == kArithPre) {
+      PreGather<NB> wg;
+      wg.init(a, f, begin, len, lane, smem);
+      PreStage<NB> R;
+      Planes<NB> P;
+      // prologue: rating pieces + chunks of stage 0, then indices + rating of stage 1
+      wg.template load<false>(R, 0);
+      wg.put_rating(R, smem);
+      wg.template dma_issue<false>(R, smem, 0);
+      wg.template load<false>(R, clamp(1));
+      int s = 0;
+      for (; s + 2 < nfull; ++s) stage_step_pre<NB, kStepFull>(wg, P, R, smem, acc, s + 1, s + 2);
+      for (; s + 1 < nst; ++s) stage_step_pre<NB, kStepPartial>(wg, P, R, smem, acc, s + 1, s + 2);
+      stage_step_pre<NB, kStepLast>(wg, P, R, smem, acc, 0, 0);
+    } else {
     WaveGather<NB> wg;
     wg.init(a, f, begin, len, lane);
     WaveStage<NB> R;
     Planes<NB, ARITH> P;
     lds_float_ptr lds = (lds_float_ptr)smem;  // staging chunks of this wave (the LU window aliases them later)
     const float* lds_lane = smem + lane;
-    auto clamp = [&](int s) { return s < nst ? s : nst - 1; };
     // prologue: chunks + ratings of stage 0 in flight, indices of stage 1
     wg.template load_idx<false>(R, 0);
     wg.template dma_issue<false>(R, lds, 0);
@@ -1201,9 +1438,10 @@ __global__ __launch_bounds__(64, CUMF_WAVE_MIN_WAVES) void als_wave_kernel(const
     for (; s + 2 < nfull; ++s) stage_step<NB, kStepFull, ARITH>(wg, P, R, lds, lds_lane, acc, s + 1, s + 2);
     for (; s + 1 < nst; ++s) stage_step<NB, kStepPartial, ARITH>(wg, P, R, lds, lds_lane, acc, s + 1, s + 2);
     stage_step<NB, kStepLast, ARITH>(wg, P, R, lds, lds_lane, acc, 0, 0);  // the last stage prefetches nothing
+    }
   }
   if constexpr (ARITH == kArithFast) fast_unscale<NB, 1, 0>(acc, a.fast_flag);
-  if constexpr (ARITH == kArithSplit3) {
+  if constexpr (ARITH != kArithFast) {
 #if CUMF_ABLATE
     if (!(a.dbg & 2))
 #endif
@@ -1433,7 +1671,7 @@ hipError_t wave_solve_launch<CUMF_WAVE_NB>(const KernelArgs& a, int mode, long n
 // ---- part 1: the LU form of the wave-per-item kernel
 template <int NB, int FC, int ARITH, bool WHOLE>
 static hipError_t launch_wave_lu_w(const KernelArgs& a, long n_items, hipStream_t stream) {
-  const size_t stage_lds = wave_stage_lds_floats<NB>() * sizeof(float);
+  const size_t stage_lds = wave_stage_lds_floats<NB, ARITH>() * sizeof(float);
   const size_t lu_lds = wave_lu_lds_floats<NB>(a.f) * sizeof(float);
   const size_t lds = lu_lds > stage_lds ? lu_lds : stage_lds;
   if (lds > 64 * 1024) {
@@ -1456,9 +1694,14 @@ hipError_t wave_lu_launch<CUMF_WAVE_NB>(const KernelArgs& a, long n_items, hipSt
 #if CUMF_WAVE_NB == 7
   // the reference's own specialisation: get_hermitian100 for f == 100 (als.cu:788-817)
   if (a.f == 100)
-    return a.fast_words ? launch_wave_lu<7, 100, kArithFast>(a, n_items, stream)
-                        : launch_wave_lu<7, 100, kArithSplit3>(a, n_items, stream);
+    return a.pre_words    ? launch_wave_lu<7, 100, kArithPre>(a, n_items, stream)
+           : a.fast_words ? launch_wave_lu<7, 100, kArithFast>(a, n_items, stream)
+                          : launch_wave_lu<7, 100, kArithSplit3>(a, n_items, stream);
 #endif
+#if CUMF_WAVE_PRE
+  if (a.pre_words) return launch_wave_lu<CUMF_WAVE_NB, 0, kArithPre>(a, n_items, stream);
+#endif
+  if (a.pre_words) return hipErrorInvalidValue;
   return a.fast_words ? launch_wave_lu<CUMF_WAVE_NB, 0, kArithFast>(a, n_items, stream)
                       : launch_wave_lu<CUMF_WAVE_NB, 0, kArithSplit3>(a, n_items, stream);
 }
@@ -1470,12 +1713,15 @@ hipError_t wave_lu_launch<CUMF_WAVE_NB>(const KernelArgs& a, long n_items, hipSt
 // ----------------------------------------------------------------------------------
 template <int NB, int FC, int ARITH>
 static hipError_t launch_wave_fc(const KernelArgs& a, int mode, long n_items, hipStream_t stream) {
-  const size_t stage_lds = wave_stage_lds_floats<NB>() * sizeof(float);
+  const size_t stage_lds = wave_stage_lds_floats<NB, ARITH>() * sizeof(float);
   if (mode == kModeMaterialize) {
-    if constexpr (ARITH != kArithSplit3) return hipErrorInvalidValue;  // materialise: the 24-bit arithmetic only
-    note_item_kernel(reinterpret_cast<const void*>(als_wave_kernel<NB, kModeMaterialize, FC, kArithSplit3>));
-    hipLaunchKernelGGL((als_wave_kernel<NB, kModeMaterialize, FC, kArithSplit3>), dim3((unsigned)n_items), dim3(64),
-                       stage_lds, stream, a);
+    if constexpr (ARITH != kArithSplit3) {
+      return hipErrorInvalidValue;  // materialise: the 24-bit arithmetic on the fp32 table only
+    } else {
+      note_item_kernel(reinterpret_cast<const void*>(als_wave_kernel<NB, kModeMaterialize, FC, kArithSplit3>));
+      hipLaunchKernelGGL((als_wave_kernel<NB, kModeMaterialize, FC, kArithSplit3>), dim3((unsigned)n_items), dim3(64),
+                         stage_lds, stream, a);
+    }
   } else if (mode == kModeCG) {
     note_item_kernel(reinterpret_cast<const void*>(als_wave_kernel<NB, kModeCG, FC, ARITH>));
     hipLaunchKernelGGL((als_wave_kernel<NB, kModeCG, FC, ARITH>), dim3((unsigned)n_items), dim3(64), stage_lds, stream, a);
@@ -1516,14 +1762,59 @@ hipError_t wave_item_launch<CUMF_WAVE_NB>(const KernelArgs& a, int mode, long n_
 #if CUMF_WAVE_NB == 7
   // the reference's own specialisation: get_hermitian100 for f == 100 (als.cu:788-817)
   if (a.f == 100)
-    return a.fast_words ? launch_wave_fc<7, 100, kArithFast>(a, mode, n_items, stream)
-                        : launch_wave_fc<7, 100, kArithSplit3>(a, mode, n_items, stream);
+    return a.pre_words    ? launch_wave_fc<7, 100, kArithPre>(a, mode, n_items, stream)
+           : a.fast_words ? launch_wave_fc<7, 100, kArithFast>(a, mode, n_items, stream)
+                          : launch_wave_fc<7, 100, kArithSplit3>(a, mode, n_items, stream);
 #endif
+#if CUMF_WAVE_PRE
+  if (a.pre_words) return launch_wave_fc<CUMF_WAVE_NB, 0, kArithPre>(a, mode, n_items, stream);
+#endif
+  if (a.pre_words) return hipErrorInvalidValue;
   return a.fast_words ? launch_wave_fc<CUMF_WAVE_NB, 0, kArithFast>(a, mode, n_items, stream)
                       : launch_wave_fc<CUMF_WAVE_NB, 0, kArithSplit3>(a, mode, n_items, stream);
 #endif
 }
 
 #endif  // CUMF_WAVE_PART == 0
+
+#if CUMF_WAVE_PART == 0 && CUMF_WAVE_NB == 7
+// ----------------------------------------------------------------------------------
+// The gather table as bf16 h | m | l planes (kArithPre; one launch per half-iteration on the launch stream: the factors
+// change every half-iteration -- 7 MB read + 11 MB written for the Netflix X table).  One thread per value; the split is
+// split3_pair's, the instruction sequence of the in-kernel split: the planes are the same bits.
+// ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void presplit_bf16x3_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
+                                                              long long n, int f, int fb, unsigned pitch_halfs) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const long long row = i / f;
+  const int k = (int)(i - row * f);
+  unsigned H, M, L;
+  split3_pair(src[i], 0.f, H, M, L);
+  unsigned short* r = dst + row * pitch_halfs;
+  if (k < 16 * fb) {
+    r[k] = (unsigned short)H;
+    r[16 * fb + k] = (unsigned short)M;
+    r[32 * fb + k] = (unsigned short)L;
+  } else {  // strip: [h 4][m 4][l 4][0 4]
+    const int e = k - 16 * fb;
+    unsigned short* st = r + 48 * fb;
+    st[e] = (unsigned short)H;
+    st[4 + e] = (unsigned short)M;
+    st[8 + e] = (unsigned short)L;
+    st[12 + e] = 0;
+  }
+}
+hipError_t launch_presplit3(const float* src, void* dst, long long rows, int f, hipStream_t stream) {
+  const long long n = rows * f;
+  if (n <= 0) return hipSuccess;
+  if (!presplit_shape_ok(f)) return hipErrorInvalidValue;
+  const int fb = f / 16;
+  const unsigned pitch = 96u * fb + (((f & 15) >> 2) ? 32u : 0u);
+  hipLaunchKernelGGL(presplit_bf16x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src,
+                     static_cast<unsigned short*>(dst), n, f, fb, pitch / 2);
+  return hipGetLastError();
+}
+#endif
 
 }  // namespace cumf

@@ -21,7 +21,7 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 C_SYMBOLS = [
     "cumf_doALS", "cumf_doALS_ex", "cumf_plan_create", "cumf_plan_destroy", "cumf_plan_info", "cumf_plan_set_gather_rows", "cumf_gram_fast_status",
     "cumf_fused_available", "cumf_als_update_fused", "cumf_fused_sse_available", "cumf_als_update_fused_sse", "cumf_quadratic_sse_terms", "cumf_get_hermitian", "cumf_get_hermitian_packed", "cumf_get_hermitian_fp16", "cumf_cg_solve_batched_fp16", "cumf_set_tt_fp16", "cumf_get_tt_fp16", "cumf_cg_solve_batched", "cumf_lu_solve_batched",
-    "cumf_pack_upper", "cumf_unpack_upper", "cumf_sse", "cumf_set_gram_mode", "cumf_get_gram_mode", "cumf_check_gather_table", "cumf_set_kernel_timing", "cumf_last_kernel_ms", "cumf_kernel_ms_since_reset", "cumf_last_kernel_name", "cumf_last_error", "cumf_release_scratch", "cumf_rand_init", "cumf_widen_rowptr", "cumf_als_version", "cumf_als_arch",
+    "cumf_pack_upper", "cumf_unpack_upper", "cumf_sse", "cumf_set_gram_mode", "cumf_get_gram_mode", "cumf_set_presplit", "cumf_get_presplit", "cumf_presplit_pitch", "cumf_presplit_table", "cumf_check_gather_table", "cumf_set_kernel_timing", "cumf_last_kernel_ms", "cumf_kernel_ms_since_reset", "cumf_last_kernel_name", "cumf_last_error", "cumf_release_scratch", "cumf_rand_init", "cumf_widen_rowptr", "cumf_als_version", "cumf_als_arch",
 ]
 # C++-linkage drop-in symbols (include/als.h, include/cg.h) under the reference's mangled names
 CXX_SYMBOLS = [
@@ -101,6 +101,14 @@ def load():
     lib.cumf_unpack_upper.argtypes = [fp, fp, C.c_long, C.c_int, vp]
     lib.cumf_set_gram_mode.restype = C.c_int
     lib.cumf_set_gram_mode.argtypes = [C.c_int]
+    lib.cumf_set_presplit.restype = C.c_int
+    lib.cumf_set_presplit.argtypes = [C.c_int]
+    lib.cumf_get_presplit.restype = C.c_int
+    lib.cumf_get_presplit.argtypes = []
+    lib.cumf_presplit_pitch.restype = C.c_long
+    lib.cumf_presplit_pitch.argtypes = [C.c_int]
+    lib.cumf_presplit_table.restype = C.c_int
+    lib.cumf_presplit_table.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p]
     lib.cumf_get_gram_mode.restype = C.c_int
     lib.cumf_check_gather_table.restype = C.c_int
     lib.cumf_check_gather_table.argtypes = [C.c_long, C.c_int, C.c_int, C.c_int]

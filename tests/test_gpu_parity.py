@@ -61,7 +61,7 @@ def test_gram_whole_rows_bit_exact(oracle, alslib, f):
     np.testing.assert_array_equal(rhs.cpu().numpy(), b_o)
 
 
-@pytest.mark.parametrize("f", [20, 30, 64, 100, 110])
+@pytest.mark.parametrize("f", [20, 30, 48, 56, 64, 100, 110])
 def test_split_gram_error_class(oracle, alslib, f):
     """Default Gram arithmetic (als_wave.hip): every fp32 value split exactly into three bf16
     terms, products hh + hm + mh + mm + hl + lh on v_mfma_f32_16x16x32_bf16, fp32 accumulation.
@@ -556,7 +556,10 @@ def test_reference_cxx_entry_points(oracle, alslib, f):
 
 @pytest.mark.parametrize("gram_mode", ["exact", "auto", "fast"], indirect=True)
 @pytest.mark.parametrize("solver,f", [("cg", 10), ("cg", 100), ("cg", 128), ("lu", 10), ("lu", 100), ("lu", 128),
-                                      ("lu", 200), ("lu", 98), ("lu", 110), ("lu", 96), ("lu", 206), ("cg", 98)])
+                                      ("lu", 200), ("lu", 98), ("lu", 110), ("lu", 96), ("lu", 206), ("cg", 98),
+                                      # NB = 4 (f = 48 .. 63), the one instance of the one-wave kernels -- and of
+                                      # the four-product diagonal tiles' doubled plane -- no matrix covered; NB = 5 with a strip
+                                      ("lu", 48), ("lu", 56), ("cg", 48), ("cg", 56), ("lu", 64), ("lu", 68)])
 def test_fused_half_iteration(oracle, alslib, gram_mode, solver, f):
     _need_gpu()
     from cumf_als_amd import als
@@ -999,3 +1002,57 @@ def test_fused_train_sse_large_f_and_chunked_rows(oracle, alslib, f, chunk, solv
         print(f"fused train SSE ({solver}) f={f} chunk={chunk} iter {it}: fused {got:.6f} kernel {kern:.6f} oracle64 {ref:.6f}  "
               f"rel {abs(got - kern) / kern:.2e}")
         assert abs(got - kern) <= 2e-5 * kern and abs(got - ref) <= 2e-5 * ref, (got, kern, ref)
+
+
+def _presplit_tool():
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("presplit_check", os.path.join(root, "tools", "presplit_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("f", [100, 64, 96, 68])
+def test_presplit_planes_are_the_in_kernel_split(alslib, f):
+    """Round 6 (kArithPre): the pre-split gather table holds, per value, exactly the three bf16 terms the in-kernel split
+    produces -- checked against a numpy restatement of the split (round to nearest even, exact residuals) over 17 decades
+    of magnitude, and h + m + l == x exactly."""
+    _need_gpu()
+    o = _presplit_tool().check_planes(f)
+    assert o["planes_equal_numpy_split"] and o["h_plus_m_plus_l_exact"], o
+
+
+@pytest.mark.parametrize("solver", ["lu", "cg"])
+@pytest.mark.parametrize("f", [100, 64, 96, 68])
+def test_presplit_is_bit_identical(alslib, f, solver):
+    """The fused half-iteration from the pre-split table (16-byte LDS-DMA + transposing LDS reads) against the same call with
+    the in-kernel split: same operands in the same MFMA K slots, so the factors -- and the fused train SSE bins -- must be
+    BIT-IDENTICAL, over rows of 0, 1, 31, 32, 33, ... ratings, a chunked row of 9 000 and 150 random ones."""
+    _need_gpu()
+    o = _presplit_tool().check_fused(f, solver)
+    assert o["kernel_on"].split(",")[3].strip() == "2" and o["kernel_off"].split(",")[3].strip() == "0", o
+    assert o["bit_identical"] and o["sse_bins_identical"] in (True, None), o
+
+
+def test_presplit_auto_follows_the_table_size(alslib, monkeypatch):
+    """CUMF_PRESPLIT_AUTO: a table whose planes fit the cache budget (64 MB) takes the pre-split kernels, a larger one (the
+    Netflix X side gathers 192 MB of Theta) keeps the fp32 table: there the bytes are the roof."""
+    _need_gpu()
+    from cumf_als_amd import als
+
+    f = 100
+    rng = np.random.RandomState(0)
+    lens = rng.randint(1, 200, 64)
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    plan = als.Plan(indptr, f)
+    for n_rows, want in ((5000, "2"), (200000, "0")):   # 3 MB / 122 MB of planes
+        idx = torch.from_numpy(rng.randint(0, n_rows, int(indptr[-1])).astype(np.int32)).cuda()
+        val = torch.ones(int(indptr[-1]), device="cuda")
+        table = torch.rand((n_rows, f), device="cuda")
+        x = torch.zeros((len(lens), f), device="cuda")
+        als.update_fused(plan, idx, val, table, x, 0.05, "lu", 6)
+        torch.cuda.synchronize()
+        assert als.last_kernel_name().split(",")[3].strip() == want, (n_rows, als.last_kernel_name())
