@@ -348,18 +348,19 @@ def get_gram_mode() -> str:
     return {GRAM_EXACT: "exact", GRAM_FAST: "fast"}.get(_libmod.load().cumf_get_gram_mode(), "auto")
 
 
-PRESPLIT_AUTO, PRESPLIT_OFF, PRESPLIT_ON = -1, 0, 1
+PRESPLIT_AUTO, PRESPLIT_OFF, PRESPLIT_ON, PRESPLIT_VERIFY = -1, 0, 1, 2
 
 
 def set_presplit(mode) -> None:
     """Pre-split gather tables (cumf_set_presplit): "auto" = where the planes of the table stay in the caches (default),
-    "off" / "on" = never / whenever the shape allows.  Results are bit-identical either way."""
-    m = {"auto": PRESPLIT_AUTO, "off": PRESPLIT_OFF, "on": PRESPLIT_ON}.get(mode, mode)
+    "off" / "on" = never / whenever the shape allows, "verify" = on with the last feature block unpacked (bit-identical to
+    "off"; the production form multiplies that block as one packed operand: same error class, other bits)."""
+    m = {"auto": PRESPLIT_AUTO, "off": PRESPLIT_OFF, "on": PRESPLIT_ON, "verify": PRESPLIT_VERIFY}.get(mode, mode)
     _libmod.check(_libmod.load().cumf_set_presplit(int(m)), "cumf_set_presplit")
 
 
 def get_presplit() -> str:
-    return {PRESPLIT_OFF: "off", PRESPLIT_ON: "on"}.get(_libmod.load().cumf_get_presplit(), "auto")
+    return {PRESPLIT_OFF: "off", PRESPLIT_ON: "on", PRESPLIT_VERIFY: "verify"}.get(_libmod.load().cumf_get_presplit(), "auto")
 
 
 def presplit_table(table: "torch.Tensor") -> "torch.Tensor":

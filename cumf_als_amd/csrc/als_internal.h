@@ -91,7 +91,8 @@ struct KernelArgs {
   int fast_words;
   int* fast_flag;
   // round 6 (kArithPre): `gather` points at the pre-split bf16 h | m | l planes of the factor table (presplit_bf16x3_kernel),
-  // rows of pre_pitch bytes
+  // rows of pre_pitch bytes.  1: the production form (packed last block, kArithPrePk), 2: the verification form (kArithPre,
+  // bit-identical to the in-kernel split)
   int pre_words;
   unsigned pre_pitch;
   // fused train SSE (als.cu:979-991 folded into the Theta update): when not null, every whole-row item of a wave-kernel

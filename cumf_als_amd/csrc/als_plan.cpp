@@ -456,7 +456,8 @@ int g_presplit_mode = -2;  // -2: not read yet; CUMF_PRESPLIT_*
 int presplit_mode() {
   if (g_presplit_mode == -2) {
     const char* env = getenv("CUMF_ALS_PRESPLIT");
-    g_presplit_mode = (env && env[0] == '0') ? CUMF_PRESPLIT_OFF : (env && env[0] == '1') ? CUMF_PRESPLIT_ON : CUMF_PRESPLIT_AUTO;
+    g_presplit_mode = (env && env[0] == '0') ? CUMF_PRESPLIT_OFF : (env && env[0] == '1') ? CUMF_PRESPLIT_ON
+                      : (env && env[0] == '2') ? CUMF_PRESPLIT_VERIFY : CUMF_PRESPLIT_AUTO;
   }
   return g_presplit_mode;
 }
@@ -465,7 +466,7 @@ bool presplit_wanted(const cumf_plan_t* p, int f, int mode) {
   const int pm = presplit_mode();
   if (pm == CUMF_PRESPLIT_OFF) return false;
   if (gram_mode() != kGramAuto || !wave_path_available(f, mode) || !presplit_supported(f) || p->gather_rows <= 0) return false;
-  if (pm == CUMF_PRESPLIT_ON) return true;
+  if (pm == CUMF_PRESPLIT_ON || pm == CUMF_PRESPLIT_VERIFY) return true;
   return (double)p->gather_rows * presplit_pitch(f) <= cap_mb * 1048576.0;
 }
 int pre_words(const cumf_plan_t* p, const float* gather, int f, hipStream_t stream, KernelArgs* a) {
@@ -474,7 +475,7 @@ int pre_words(const cumf_plan_t* p, const float* gather, int f, hipStream_t stre
   if (rc) return rc;
   CUMF_HIP_CHECK(launch_presplit3(gather, planes, p->gather_rows, f, stream));
   a->gather = reinterpret_cast<const float*>(planes);
-  a->pre_words = 1;
+  a->pre_words = presplit_mode() == CUMF_PRESPLIT_VERIFY ? 2 : 1;
   a->pre_pitch = presplit_pitch(f);
   return 0;
 }
@@ -787,7 +788,8 @@ extern "C" int cumf_set_gram_mode(int mode) {
 extern "C" int cumf_get_gram_mode(void) { return gram_mode(); }
 
 extern "C" int cumf_set_presplit(int mode) {
-  if (mode != CUMF_PRESPLIT_AUTO && mode != CUMF_PRESPLIT_OFF && mode != CUMF_PRESPLIT_ON) return (int)hipErrorInvalidValue;
+  if (mode != CUMF_PRESPLIT_AUTO && mode != CUMF_PRESPLIT_OFF && mode != CUMF_PRESPLIT_ON && mode != CUMF_PRESPLIT_VERIFY)
+    return (int)hipErrorInvalidValue;
   g_presplit_mode = mode;
   return 0;
 }

@@ -88,7 +88,7 @@ __device__ __forceinline__ f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 c) {
 // ds_read_b64_tr_b16, the 16-bit transposing read of gfx950 -- no split, no pack, no select on the VALU.  For gather
 // tables that live in the caches (the Netflix Theta side: X = 7 MB; the hugewiki X side: Theta = 16 MB); an HBM-resident
 // table stays fp32 (1.5 x the bytes would cost more than the VALU work saves).
-enum { kArithSplit3 = 0, kArithFast = 1, kArithPre = 2 };
+enum { kArithSplit3 = 0, kArithFast = 1, kArithPre = 2, kArithPrePk = 3 };
 constexpr float kFastScale = 4096.0f;             // values must stay below 65504 / 4096 = 15.99 in magnitude
 constexpr float kFastUnscale = 1.0f / (4096.0f * 4096.0f);
 
@@ -419,6 +419,9 @@ __device__ __forceinline__ void gram_mfma_sched(const Planes<NB>& P, f32x4 (&acc
   constexpr GramSched<NB> S = make_gram_sched<NB>();
   constexpr int t = S.tile[N], kind = S.kind[N];
   constexpr int I = tile_I<NB>(t), J = tile_J<NB>(t);
+#ifdef CUMF_EXP_STRIP  // timing experiment only (wrong results): the last tile column at 3 products / 1 on its diagonal tile
+  if constexpr (J == NB - 1 && (kind == kLH || kind == kHL || kind == kMH || kind == kD2L || kind == kD2M || (I == J && kind == kMM))) return;
+#endif
   if constexpr (kind == kLH) acc[t] = mfma_bf16(P.l[I], P.h[J], acc[t]);
   if constexpr (kind == kHL) acc[t] = mfma_bf16(P.h[I], P.l[J], acc[t]);
   if constexpr (kind == kMM) acc[t] = mfma_bf16(P.m[I], P.m[J], acc[t]);
@@ -516,7 +519,8 @@ __device__ __forceinline__ void stage_step(const WaveGather<NB>& wg, Planes<NB, 
 }
 
 // ----------------------------------------------------------------------------------
-// kArithPre: the stage on a pre-split gather table (round 6; tools/probes/tr16_dma_probe.hip pins the two instructions).
+// kArithPre / kArithPrePk: the stage on a pre-split gather table (round 6; tools/probes/tr16_dma_probe.hip pins the two
+// instructions it is built on).
 //
 // Table row (presplit_bf16x3_kernel), FB = f / 16 full feature blocks, SP = (f % 16) / 4 in {0, 1} strip pieces:
 //   [h: 16 FB bf16][m: 16 FB bf16][l: 16 FB bf16] [strip, if SP: h, m, l of features 16 FB .. 16 FB + 3 (8 B each) + 8 B of zeros]
@@ -525,18 +529,29 @@ __device__ __forceinline__ void stage_step(const WaveGather<NB>& wg, Planes<NB, 
 //           by ONE global_load_lds_dwordx4 (lane l = LP q + piece: 16 bytes -> chunk + 16 l; the lanes behind the 2 FB pieces
 //           of a rating are masked off); 24 chunks instead of 56 dword gathers.  RP = 192 (64 for FB <= 2) and a 32-byte
 //           skew per E pair put the eight 32-byte row pieces a transposing read touches per half wave into eight bank groups.
-//   strip   [rho][h 8 B | m 8 B | l 8 B | 0] of the 32 ratings: one more 16-byte LDS-DMA (lane l: rating l / 2, half l % 2)
-//   rating  [rho][r_h 0 0 0 | r_m 0 0 0 | r_l 0 0 0]: the rating value rides in slot f (als.cu:750-757 fused into the Gram);
-//           it is no table entry, so lane rho splits the value of rating rho of the NEXT stage and stores three halfwords
+//   strip   [rho][h 8 B | m 8 B | l 8 B | pad 8 B] of the 32 ratings: one more 16-byte LDS-DMA (lane l: rating l / 2, half l % 2)
+//   rating  the rating value rides in slot f (als.cu:750-757 fused into the Gram) and is no table entry: lane rho splits the
+//           value of rating rho of the stage (loaded a stage ahead) and stores it once the stage's chunks have landed --
+//           kArithPrePk: [r_h r_m r_l 0] as ONE 8-byte store into the strip's pad; kArithPre: [r_h 0 0 0 | r_m 0 0 0 | r_l 0 0 0]
 //   zeros   24 bytes: what the lanes behind slot f read
 // Operands: ds_read_b64_tr_b16 hands lane 4 a + b of a 16-lane group, as element j, halfword b of the 8-byte piece that lane
 // 4 j + a addresses.  Lane (g, 4 j + a) addresses features 16 B + 4 a .. + 3 of rating rho = 8 g + 4 u + j: lane (g, c) receives
 // feature 16 B + c of the ratings 8 g + 4 u + 0 .. 3 -- K slots 4 u .. 4 u + 3 of the MFMA, exactly the slots the in-kernel
-// split gives them (P.h[B][2 u], [2 u + 1]); same operands in the same slots, same MFMA sequence: the accumulators are
-// bit-identical to kArithSplit3's (tests/test_gpu_parity.py::test_presplit_is_bit_identical).
+// split gives them (P.h[B][2 u], [2 u + 1]).
+//   kArithPre    every block like that, the last one from strip / rating pieces per plane: same operands in the same slots,
+//                same MFMA sequence -- the accumulators are BIT-IDENTICAL to kArithSplit3's
+//                (tests/test_gpu_parity.py::test_presplit_is_bit_identical); the verification form (cumf_set_presplit(2)).
+//   kArithPrePk  the production form: the last feature block (f = 100: four features + the rating, 11 of 16 columns zero) is
+//                read as ONE packed operand pk whose columns are [h of the strip features | m | l | r_h r_m r_l 0]: tile
+//                (I, NB - 1) takes three products h_I pk + m_I pk + l_I pk (all nine plane products at once) instead of six,
+//                tile (NB - 1, NB - 1) one (pk pk^T) instead of four -- 133 MFMAs per stage instead of 154 at f = 100 -- and
+//                once per item the column groups are folded back (wave_fold_strip).  Error class of kArithSplit3 (the three
+//                dropped products ml, lm, ll are now included), not its bits in the last block column.
 // ----------------------------------------------------------------------------------
+__host__ __device__ constexpr bool presplit_shape_ok(int f) { return (f & 15) == 0 || (f & 15) == 4; }
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4* lds_tr_ptr;
+typedef char __attribute__((address_space(3)))* lds_byte_ptr;
 template <int NB>
 struct PreGeo {
   static constexpr int FB = NB - 1;
@@ -545,24 +560,26 @@ struct PreGeo {
   static constexpr int CS = 4 * RP;                   // one chunk: a plane of four ratings
   static constexpr int kMain = 24 * CS + 3 * 32;      // + the skews: chunk (E, p) at (3 E + p) CS + 32 (E >> 1)
   static constexpr int kStrip = kMain;                // 32 ratings x 32 B
-  static constexpr int kRating = kStrip + 1024;       // 32 ratings x 24 B
-  static constexpr int kZero = kRating + 768;         // 24 B (32 reserved)
-  static constexpr int kBytes = kZero + 32;
+  static constexpr int kZero = kStrip + 1024;         // 24 B (32 reserved)
+  static constexpr int kRating = kZero + 32;          // kArithPre only: 32 ratings x 24 B
+  __host__ __device__ static constexpr int bytes(bool packed) { return packed ? kRating : kRating + 768; }
   static_assert(32 * FB <= RP && 4 * LP <= 64, "a rating's plane fits its slot, four ratings fit the wave");
   __host__ __device__ static constexpr int chunk(int E, int p) { return (3 * E + p) * CS + 32 * (E >> 1); }
-  // row pitch of the table in bytes (a multiple of 16: the 16-byte LDS-DMA needs aligned sources)
-  __host__ __device__ static constexpr unsigned pitch(int f) { return 96u * FB + (((f & 15) >> 2) ? 32u : 0u); }
 };
-__host__ __device__ constexpr bool presplit_shape_ok(int f) { return (f & 15) == 0 || (f & 15) == 4; }
 
 template <int NB>
 struct PreStage {
   int idx[8];   // column indices of the ratings 4 E + q of a stage whose main chunks are still to be issued (lanes of DMA group q)
   int sidx;     // ... of rating lane / 2 (strip)
-  float rv;     // rating value of rating lane & 31
+  float rv;     // rating value of rating lane & 31 of the stage whose chunks are in flight
+};
+template <int NB>
+struct Planes<NB, kArithPrePk> {
+  u32x4 h[NB], m[NB], l[NB];  // blocks 0 .. NB - 2
+  u32x4 pk;                   // the last block, packed
 };
 
-template <int NB>
+template <int NB, bool PK>
 struct PreGather {
   using G = PreGeo<NB>;
   const char* lane_base;   // table + 16 piece
@@ -572,7 +589,7 @@ struct PreGather {
   const int* ib;           // colidx + begin (the zero row for an item without ratings)
   const float* vb;         // val + begin (the zero row without ratings / values)
   lds_tr_ptr tr_main;      // lane part of the addresses of the transposing reads of blocks 0 .. FB - 1
-  lds_tr_ptr tr_last[2];   // ... of the last block, per quad u: strip piece / rating piece / zeros
+  lds_tr_ptr tr_last[2];   // ... of the last block, per quad u
   unsigned pitch;
   int len, q, lane;
   bool dma_active, sp;
@@ -593,51 +610,70 @@ struct PreGather {
     ib = len_ > 0 ? a.colidx + begin : reinterpret_cast<const int*>(g_wave_zeros);
     vb = (len_ > 0 && a.val != nullptr) ? a.val + begin : g_wave_zeros;
     const int g = lane >> 4, j = (lane >> 2) & 3, aa = lane & 3;
-    char __attribute__((address_space(3)))* base = (char __attribute__((address_space(3)))*)smem;
+    lds_byte_ptr base = (lds_byte_ptr)smem;
     tr_main = (lds_tr_ptr)(base + 6 * g * G::CS + 32 * g + G::RP * j + 8 * aa);
+    const int spn = sp ? 1 : 0;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int rho = 8 * g + 4 * u + j;
-      const int spn = sp ? 1 : 0;
-      const int off = aa < spn ? G::kStrip + 32 * rho + 8 * aa : (aa == spn ? G::kRating + 24 * rho : G::kZero);
+      int off;
+      if constexpr (PK)  // columns [h feats | m feats | l feats | rating]: the strip's pieces in order, the rating piece in its pad
+        off = (sp || aa == 0) ? G::kStrip + 32 * rho + (sp ? 8 * aa : 24) : G::kZero;
+      else
+        off = aa < spn ? G::kStrip + 32 * rho + 8 * aa : (aa == spn ? G::kRating + 24 * rho : G::kZero);
       tr_last[u] = (lds_tr_ptr)(base + off);
     }
-    // the rating pieces' zero halfwords and the zero pieces, once (LDS operations of one wave execute in order)
-    if (lane < (768 + 32) / 16) reinterpret_cast<f32x4*>(reinterpret_cast<char*>(smem) + G::kRating)[lane] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // the zero pieces (and the rating pieces' zero halfwords), once (LDS operations of one wave execute in order)
+    constexpr int kClear = (G::bytes(PK) - G::kZero) / 16;
+    if (lane < kClear) reinterpret_cast<f32x4*>(reinterpret_cast<char*>(smem) + G::kZero)[lane] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  // indices + rating value of stage s (FULL: every rating of the stage exists)
+  // column indices of stage s (FULL: every rating of the stage exists)
   template <bool FULL>
-  __device__ __forceinline__ void load(PreStage<NB>& st, int s) const {
+  __device__ __forceinline__ void load_idx(PreStage<NB>& st, int s) const {
     const int top = len > 0 ? len - 1 : 0;
     if constexpr (FULL) {
       const int* p = ib + kWaveStage * s + q;
 #pragma unroll
       for (int E = 0; E < 8; ++E) st.idx[E] = p[4 * E];
       st.sidx = ib[kWaveStage * s + (lane >> 1)];
-      st.rv = vb[kWaveStage * s + (lane & 31)];
     } else {
 #pragma unroll
       for (int E = 0; E < 8; ++E) {
         const int pos = kWaveStage * s + 4 * E + q;
         st.idx[E] = ib[pos < top ? pos : top];
       }
-      const int ps = kWaveStage * s + (lane >> 1), pv = kWaveStage * s + (lane & 31);
+      const int ps = kWaveStage * s + (lane >> 1);
       st.sidx = ib[ps < top ? ps : top];
+    }
+  }
+  // rating value of stage s; ratings past the end of the item: zero rows AND a zero rating (sum r^2 of the fused SSE)
+  template <bool FULL>
+  __device__ __forceinline__ void load_rv(PreStage<NB>& st, int s) const {
+    const int pv = kWaveStage * s + (lane & 31);
+    if constexpr (FULL) {
+      st.rv = vb[pv];
+    } else {
+      const int top = len > 0 ? len - 1 : 0;
       const float v = vb[pv < top ? pv : top];
-      st.rv = pv < len ? v : 0.f;  // ratings past the end of the item: zero rows AND a zero rating (sum r^2 of the fused SSE)
+      st.rv = pv < len ? v : 0.f;
     }
   }
 
-  // the rating value of stage s (in st.rv) as three bf16 terms into the rating pieces
+  // the rating values of the stage that has just landed (st.rv) as three bf16 terms into its rating pieces
   __device__ __forceinline__ void put_rating(const PreStage<NB>& st, float* smem) const {
     unsigned H, M, L;
     split3_pair(st.rv, 0.f, H, M, L);
     if (lane < 32) {
-      unsigned short* rp = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(smem) + G::kRating + 24 * lane);
-      rp[0] = (unsigned short)H;
-      rp[4] = (unsigned short)M;
-      rp[8] = (unsigned short)L;
+      if constexpr (PK) {
+        u32x2 w = {(H & 0xffffu) | (M << 16), L & 0xffffu};
+        *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(smem) + G::kStrip + 32 * lane + 24) = w;
+      } else {
+        unsigned short* rp = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(smem) + G::kRating + 24 * lane);
+        rp[0] = (unsigned short)H;
+        rp[4] = (unsigned short)M;
+        rp[8] = (unsigned short)L;
+      }
     }
   }
 
@@ -646,7 +682,7 @@ struct PreGather {
 #if defined(__HIP_DEVICE_COMPILE__)  // (the host pass of hipcc rejects the 16-byte form of the builtin: it checks it against the host target)
     using gptr = const __attribute__((address_space(1))) void*;
     using lptr = __attribute__((address_space(3))) void*;
-    char __attribute__((address_space(3)))* lds = (char __attribute__((address_space(3)))*)smem;
+    lds_byte_ptr lds = (lds_byte_ptr)smem;
     if (dma_active) {
       static_for<8>([&](auto ec) {
         constexpr int E = decltype(ec)::value;
@@ -668,59 +704,184 @@ struct PreGather {
   }
 
   // the landed stage -> MFMA operands
-  __device__ __forceinline__ void read(Planes<NB>& P) const {
-    auto rd = [](lds_tr_ptr p, int byte_off) {
-      return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                                            (lds_tr_ptr)((char __attribute__((address_space(3)))*)p + byte_off)));
-    };
-    static_for<NB>([&](auto bc) {
+  static __device__ __forceinline__ u32x2 tr_read(lds_tr_ptr p, int byte_off) {
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)((lds_byte_ptr)p + byte_off)));
+  }
+  template <class PL>
+  __device__ __forceinline__ void read(PL& P) const {
+    static_for<G::FB>([&](auto bc) {
       constexpr int B = decltype(bc)::value;
       static_for<2>([&](auto uc) {
         constexpr int u = decltype(uc)::value;
-        u32x2 vh, vm, vl;
-        if constexpr (B < G::FB) {
-          vh = rd(tr_main, (3 * u + 0) * G::CS + 32 * B);
-          vm = rd(tr_main, (3 * u + 1) * G::CS + 32 * B);
-          vl = rd(tr_main, (3 * u + 2) * G::CS + 32 * B);
-        } else {
-          vh = rd(tr_last[u], 0);
-          vm = rd(tr_last[u], 8);
-          vl = rd(tr_last[u], 16);
-        }
+        const u32x2 vh = tr_read(tr_main, (3 * u + 0) * G::CS + 32 * B);
+        const u32x2 vm = tr_read(tr_main, (3 * u + 1) * G::CS + 32 * B);
+        const u32x2 vl = tr_read(tr_main, (3 * u + 2) * G::CS + 32 * B);
         P.h[B][2 * u] = vh[0], P.h[B][2 * u + 1] = vh[1];
         P.m[B][2 * u] = vm[0], P.m[B][2 * u + 1] = vm[1];
         P.l[B][2 * u] = vl[0], P.l[B][2 * u + 1] = vl[1];
       });
     });
+    // the last block (no generic lambda here: the form not taken must be discarded, not just skipped)
+    if constexpr (PK) {
+      const u32x2 v0 = tr_read(tr_last[0], 0), v1 = tr_read(tr_last[1], 0);
+      P.pk = u32x4{v0[0], v0[1], v1[0], v1[1]};
+    } else {
+      constexpr int B = G::FB;
+      const u32x2 h0 = tr_read(tr_last[0], 0), m0 = tr_read(tr_last[0], 8), l0 = tr_read(tr_last[0], 16);
+      const u32x2 h1 = tr_read(tr_last[1], 0), m1 = tr_read(tr_last[1], 8), l1 = tr_read(tr_last[1], 16);
+      P.h[B] = u32x4{h0[0], h0[1], h1[0], h1[1]};
+      P.m[B] = u32x4{m0[0], m0[1], m1[0], m1[1]};
+      P.l[B] = u32x4{l0[0], l0[1], l1[0], l1[1]};
+    }
   }
 };
 
-// One stage: wait for the chunks -> 6 NB transposing reads -> rating pieces + chunks of the next stage, indices + rating of
-// the one after -> MFMAs (the same schedule as kArithSplit3).  R holds what was loaded a step ago: the stage s_next.
-template <int NB, int KIND>
-__device__ __forceinline__ void stage_step_pre(const PreGather<NB>& wg, Planes<NB>& P, PreStage<NB>& R, float* smem,
+// MFMA schedule of kArithPrePk: as make_gram_sched on the full blocks (six products, four on their diagonal tiles); the last
+// block column three products against the packed operand (kPL, kPM, kPH: small terms first), its diagonal tile one (kPP).
+enum { kPL = 8, kPM = 9, kPH = 10, kPP = 11 };
+template <int NB>
+struct GramSchedPk {
+  static constexpr int FB = NB - 1, NTF = FB * (FB + 1) / 2;
+  static constexpr int N = 6 * NTF - 2 * FB + 3 * FB + 1;
+  int tile[N], kind[N];
+};
+template <int NB>
+__host__ __device__ constexpr GramSchedPk<NB> make_gram_sched_pk() {
+  constexpr int FB = NB - 1, NTF = FB * (FB + 1) / 2, NOFF = NTF - FB;
+  GramSchedPk<NB> s{};
+  int off[NOFF > 0 ? NOFF : 1] = {}, dg[FB > 0 ? FB : 1] = {}, st[FB > 0 ? FB : 1] = {};
+  int no = 0;
+  for (int I = 0; I < FB; ++I) {
+    dg[I] = tile_of<NB>(I, I);
+    st[I] = tile_of<NB>(I, NB - 1);
+    for (int J = I + 1; J < FB; ++J) off[no++] = tile_of<NB>(I, J);
+  }
+  int n = 0;
+  for (int k = 0; k < NOFF; ++k) { s.tile[n] = off[k]; s.kind[n++] = kLH; }
+  for (int I = 0; I < FB; ++I) { s.tile[n] = st[I]; s.kind[n++] = kPL; }
+  for (int k = 0; k < NOFF; ++k) { s.tile[n] = off[k]; s.kind[n++] = kHL; }
+  int used = 0;  // separators inside the diagonal triples: off-diagonal mm products, then the strip's m products
+  for (int I = 0; I < FB; ++I) {
+    s.tile[n] = dg[I]; s.kind[n++] = kD2L;
+    if (used < NOFF) { s.tile[n] = off[used++]; s.kind[n++] = kMM; }
+    else { s.tile[n] = st[used - NOFF]; s.kind[n++] = kPM; ++used; }
+    s.tile[n] = dg[I]; s.kind[n++] = kD2M;
+  }
+  for (int k = used; k < NOFF; ++k) { s.tile[n] = off[k]; s.kind[n++] = kMM; }
+  for (int k = (used > NOFF ? used - NOFF : 0); k < FB; ++k) { s.tile[n] = st[k]; s.kind[n++] = kPM; }
+  for (int I = 0; I < FB; ++I) { s.tile[n] = dg[I]; s.kind[n++] = kMM; }
+  for (int k = 0; k < NOFF; ++k) { s.tile[n] = off[k]; s.kind[n++] = kMH; }
+  for (int k = 0; k < NOFF; ++k) { s.tile[n] = off[k]; s.kind[n++] = kHM; }
+  for (int I = 0; I < FB; ++I) { s.tile[n] = st[I]; s.kind[n++] = kPH; }
+  for (int I = 0; I < FB; ++I) {
+    s.tile[n] = dg[I]; s.kind[n++] = kHH;
+    for (int J = I + 1; J < FB; ++J) { s.tile[n] = tile_of<NB>(I, J); s.kind[n++] = kHH; }
+  }
+  s.tile[n] = tile_of<NB>(NB - 1, NB - 1); s.kind[n++] = kPP;
+  return s;
+}
+template <int NB, int N>
+__device__ __forceinline__ void gram_mfma_sched_pk(const Planes<NB, kArithPrePk>& P, f32x4 (&acc)[NB * (NB + 1) / 2], u32x4 (&h2)[2]) {
+  constexpr GramSchedPk<NB> S = make_gram_sched_pk<NB>();
+  constexpr int t = S.tile[N], kind = S.kind[N];
+  constexpr int I = tile_I<NB>(t), J = tile_J<NB>(t);
+  if constexpr (kind == kLH) acc[t] = mfma_bf16(P.l[I], P.h[J], acc[t]);
+  if constexpr (kind == kHL) acc[t] = mfma_bf16(P.h[I], P.l[J], acc[t]);
+  if constexpr (kind == kMM) acc[t] = mfma_bf16(P.m[I], P.m[J], acc[t]);
+  if constexpr (kind == kMH) acc[t] = mfma_bf16(P.m[I], P.h[J], acc[t]);
+  if constexpr (kind == kHM) acc[t] = mfma_bf16(P.h[I], P.m[J], acc[t]);
+  if constexpr (kind == kHH) acc[t] = mfma_bf16(P.h[I], P.h[J], acc[t]);
+  if constexpr (kind == kD2L) {
+    h2[I & 1] = bf16x8_times2(P.h[I]);
+    acc[t] = mfma_bf16(h2[I & 1], P.l[I], acc[t]);
+  }
+  if constexpr (kind == kD2M) acc[t] = mfma_bf16(h2[I & 1], P.m[I], acc[t]);
+  if constexpr (kind == kPL) acc[t] = mfma_bf16(P.l[I], P.pk, acc[t]);
+  if constexpr (kind == kPM) acc[t] = mfma_bf16(P.m[I], P.pk, acc[t]);
+  if constexpr (kind == kPH) acc[t] = mfma_bf16(P.h[I], P.pk, acc[t]);
+  if constexpr (kind == kPP) acc[t] = mfma_bf16(P.pk, P.pk, acc[t]);
+}
+
+// kArithPrePk, once per item behind the last stage: the packed column groups of the last block column back into the
+// layout every consumer expects (columns 0 .. 4 SP - 1: the strip's features, column 4 SP: the right-hand side, zeros
+// behind).  With n = 4 SP:  G[.][j] = S[.][j] + S[.][n + j] + S[.][2 n + j],  G[.][n] = S[.][3 n] + S[.][3 n + 1] + S[.][3 n + 2];
+// the diagonal tile (NB - 1, NB - 1) = pk pk^T folds its rows the same way (rows 4 g + r: plane g of feature r, g = 3: the
+// rating's three terms) -- two ds_bpermute per register + one for the rating row.
+template <int N>
+__device__ __forceinline__ float dpp_row_shl(float v) {  // lane c of every 16-lane row reads lane c + N of its row (0 past its end)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + N, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float fold_strip_cols(float v, bool sp, int c) {
+  const float u = (v + dpp_row_shl<1>(v)) + dpp_row_shl<2>(v);  // lane 3 n: the rating's three terms
+  if (sp) {  // wave-uniform
+    const float a = (v + dpp_row_shl<4>(v)) + dpp_row_shl<8>(v);
+    const float r = dpp_row_shl<8>(u);                          // lane 4 <- lane 12
+    return c < 4 ? a : (c == 4 ? r : 0.f);
+  }
+  return c == 0 ? u : 0.f;
+}
+template <int NB>
+__device__ __forceinline__ void wave_fold_strip(f32x4 (&acc)[NB * (NB + 1) / 2], bool sp, int lane) {
+  const int c = lane & 15, g = lane >> 4;
+  auto bperm = [](int addr, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
+  };
+  static_for<NB>([&](auto ic) {
+    constexpr int t = tile_of<NB>(decltype(ic)::value, NB - 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[t][r] = fold_strip_cols(acc[t][r], sp, c);
+  });
+  constexpr int t = tile_of<NB>(NB - 1, NB - 1);
+  float w[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) w[r] = acc[t][r];
+  const float rt = (w[0] + w[1]) + w[2];  // lane group 3 (SP) / 0 (no strip): the rating row's three terms
+  if (sp) {  // wave-uniform
+    const float y = bperm(4 * ((lane + 32) & 63), rt);  // lane group 1 <- lane group 3
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float x1 = bperm(4 * ((lane + 16) & 63), w[r]), x2 = bperm(4 * ((lane + 32) & 63), w[r]);
+      const float rows = (w[r] + x1) + x2;  // lane group 0: planes h + m + l of feature row r
+      acc[t][r] = g == 0 ? rows : ((g == 1 && r == 0) ? y : 0.f);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[t][r] = (g == 0 && r == 0) ? rt : 0.f;
+  }
+}
+
+// One stage: wait for the chunks -> rating pieces -> 6 NB transposing reads -> chunks of the next stage, indices of the one
+// after, rating values of the next -> MFMAs.  At entry R holds the indices of stage s_next and the rating values of this one.
+template <int NB, int KIND, bool PK, class PL>
+__device__ __forceinline__ void stage_step_pre(const PreGather<NB, PK>& wg, PL& P, PreStage<NB>& R, float* smem,
                                                f32x4 (&acc)[NB * (NB + 1) / 2], int s_next, int s_load) {
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the chunks of this stage have landed, R is complete
+  wg.put_rating(R, smem);
   wg.read(P);
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the operands are in registers, the image is free
   if constexpr (KIND == kStepFull) {
-    wg.put_rating(R, smem);
     wg.template dma_issue<true>(R, smem, s_next);
-    wg.template load<true>(R, s_load);
+    wg.template load_idx<true>(R, s_load);
+    wg.template load_rv<true>(R, s_next);
   } else if constexpr (KIND == kStepPartial) {
     const int nfull = wg.len / kWaveStage, nst = (wg.len + kWaveStage - 1) / kWaveStage;
-    wg.put_rating(R, smem);
-    if (s_next < nfull)
+    if (s_next < nfull) {
       wg.template dma_issue<true>(R, smem, s_next);
-    else
+      wg.template load_rv<true>(R, s_next);
+    } else {
       wg.template dma_issue<false>(R, smem, s_next);
+      wg.template load_rv<false>(R, s_next);
+    }
     if (s_load < nfull)
-      wg.template load<true>(R, s_load);
+      wg.template load_idx<true>(R, s_load);
     else if (s_load < nst)
-      wg.template load<false>(R, s_load);
+      wg.template load_idx<false>(R, s_load);
   }
   u32x4 h2[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
-  static_for<GramSched<NB>::N>([&](auto nc) { gram_mfma_sched<NB, decltype(nc)::value>(P, acc, h2); });
+  if constexpr (PK)
+    static_for<GramSchedPk<NB>::N>([&](auto nc) { gram_mfma_sched_pk<NB, decltype(nc)::value>(P, acc, h2); });
+  else
+    static_for<GramSched<NB>::N>([&](auto nc) { gram_mfma_sched<NB, decltype(nc)::value>(P, acc, h2); });
 }
 
 // ----------------------------------------------------------------------------------
@@ -787,8 +948,8 @@ __host__ __device__ constexpr int wave_lu_lds_floats(int f) {
 }
 template <int NB, int ARITH = kArithSplit3>
 __host__ __device__ constexpr int wave_stage_lds_floats() {
-  if constexpr (ARITH == kArithPre)
-    return PreGeo<NB>::kBytes / 4;  // the pre-split image of a stage
+  if constexpr (ARITH == kArithPre || ARITH == kArithPrePk)
+    return PreGeo<NB>::bytes(ARITH == kArithPrePk) / 4;  // the pre-split image of a stage
   else
     return 64 * 8 * NB;             // 8 NB chunks of 64 floats
 }
@@ -1406,20 +1567,22 @@ __global__ __launch_bounds__(64, CUMF_WAVE_MIN_WAVES) void als_wave_kernel(const
 #endif
   {
     auto clamp = [&](int s) { return s < nst ? s : nst - 1; };
-    if constexpr (ARITH == kArithPre) {
-      PreGather<NB> wg;
+    if constexpr (ARITH == kArithPre || ARITH == kArithPrePk) {
+      constexpr bool PK = ARITH == kArithPrePk;
+      PreGather<NB, PK> wg;
       wg.init(a, f, begin, len, lane, smem);
       PreStage<NB> R;
-      Planes<NB> P;
-      // prologue: rating pieces + chunks of stage 0, then indices + rating of stage 1
-      wg.template load<false>(R, 0);
-      wg.put_rating(R, smem);
+      Planes<NB, PK ? kArithPrePk : kArithSplit3> P;
+      // prologue: chunks of stage 0 in flight, its rating values, the indices of stage 1
+      wg.template load_idx<false>(R, 0);
       wg.template dma_issue<false>(R, smem, 0);
-      wg.template load<false>(R, clamp(1));
+      wg.template load_rv<false>(R, 0);
+      wg.template load_idx<false>(R, clamp(1));
       int s = 0;
-      for (; s + 2 < nfull; ++s) stage_step_pre<NB, kStepFull>(wg, P, R, smem, acc, s + 1, s + 2);
-      for (; s + 1 < nst; ++s) stage_step_pre<NB, kStepPartial>(wg, P, R, smem, acc, s + 1, s + 2);
-      stage_step_pre<NB, kStepLast>(wg, P, R, smem, acc, 0, 0);
+      for (; s + 2 < nfull; ++s) stage_step_pre<NB, kStepFull, PK>(wg, P, R, smem, acc, s + 1, s + 2);
+      for (; s + 1 < nst; ++s) stage_step_pre<NB, kStepPartial, PK>(wg, P, R, smem, acc, s + 1, s + 2);
+      stage_step_pre<NB, kStepLast, PK>(wg, P, R, smem, acc, 0, 0);
+      if constexpr (PK) wave_fold_strip<NB>(acc, wg.sp, lane);
     } else {
     WaveGather<NB> wg;
     wg.init(a, f, begin, len, lane);
@@ -1694,12 +1857,15 @@ hipError_t wave_lu_launch<CUMF_WAVE_NB>(const KernelArgs& a, long n_items, hipSt
 #if CUMF_WAVE_NB == 7
   // the reference's own specialisation: get_hermitian100 for f == 100 (als.cu:788-817)
   if (a.f == 100)
-    return a.pre_words    ? launch_wave_lu<7, 100, kArithPre>(a, n_items, stream)
-           : a.fast_words ? launch_wave_lu<7, 100, kArithFast>(a, n_items, stream)
-                          : launch_wave_lu<7, 100, kArithSplit3>(a, n_items, stream);
+    return a.pre_words == 1 ? launch_wave_lu<7, 100, kArithPrePk>(a, n_items, stream)
+           : a.pre_words    ? launch_wave_lu<7, 100, kArithPre>(a, n_items, stream)
+           : a.fast_words   ? launch_wave_lu<7, 100, kArithFast>(a, n_items, stream)
+                            : launch_wave_lu<7, 100, kArithSplit3>(a, n_items, stream);
 #endif
 #if CUMF_WAVE_PRE
-  if (a.pre_words) return launch_wave_lu<CUMF_WAVE_NB, 0, kArithPre>(a, n_items, stream);
+  if (a.pre_words)
+    return a.pre_words == 1 ? launch_wave_lu<CUMF_WAVE_NB, 0, kArithPrePk>(a, n_items, stream)
+                            : launch_wave_lu<CUMF_WAVE_NB, 0, kArithPre>(a, n_items, stream);
 #endif
   if (a.pre_words) return hipErrorInvalidValue;
   return a.fast_words ? launch_wave_lu<CUMF_WAVE_NB, 0, kArithFast>(a, n_items, stream)
@@ -1762,12 +1928,15 @@ hipError_t wave_item_launch<CUMF_WAVE_NB>(const KernelArgs& a, int mode, long n_
 #if CUMF_WAVE_NB == 7
   // the reference's own specialisation: get_hermitian100 for f == 100 (als.cu:788-817)
   if (a.f == 100)
-    return a.pre_words    ? launch_wave_fc<7, 100, kArithPre>(a, mode, n_items, stream)
-           : a.fast_words ? launch_wave_fc<7, 100, kArithFast>(a, mode, n_items, stream)
-                          : launch_wave_fc<7, 100, kArithSplit3>(a, mode, n_items, stream);
+    return a.pre_words == 1 ? launch_wave_fc<7, 100, kArithPrePk>(a, mode, n_items, stream)
+           : a.pre_words    ? launch_wave_fc<7, 100, kArithPre>(a, mode, n_items, stream)
+           : a.fast_words   ? launch_wave_fc<7, 100, kArithFast>(a, mode, n_items, stream)
+                            : launch_wave_fc<7, 100, kArithSplit3>(a, mode, n_items, stream);
 #endif
 #if CUMF_WAVE_PRE
-  if (a.pre_words) return launch_wave_fc<CUMF_WAVE_NB, 0, kArithPre>(a, mode, n_items, stream);
+  if (a.pre_words)
+    return a.pre_words == 1 ? launch_wave_fc<CUMF_WAVE_NB, 0, kArithPrePk>(a, mode, n_items, stream)
+                            : launch_wave_fc<CUMF_WAVE_NB, 0, kArithPre>(a, mode, n_items, stream);
 #endif
   if (a.pre_words) return hipErrorInvalidValue;
   return a.fast_words ? launch_wave_fc<CUMF_WAVE_NB, 0, kArithFast>(a, mode, n_items, stream)

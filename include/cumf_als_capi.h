@@ -213,16 +213,20 @@ int cumf_get_gram_mode(void);
  * Round 6: where the gather table of a fused call lives in the caches (the Netflix Theta side gathers X: 7 MB; the
  * hugewiki X side gathers Theta: 16 MB) CUMF_GRAM_AUTO rewrites it per call as bf16 h | m | l planes -- the exact three-way
  * split the kernels otherwise perform on every gathered value, the same bits -- and the Gram stage reads its MFMA operands
- * from those planes (16-byte LDS-DMA + transposing LDS reads; als_wave.hip, kArithPre).  Results are bit-identical to the
- * in-kernel split.  Needs cumf_plan_set_gather_rows; f = 64..79 or 96..111 with f % 16 in {0, 4}.
+ * from those planes (16-byte LDS-DMA + transposing LDS reads; als_wave.hip, kArithPrePk); the last, mostly empty feature
+ * block is multiplied as ONE packed operand (three products instead of six).  Same arithmetic class as the in-kernel split
+ * (every plane product of the last block column is kept, the rest is the same operation for operation).  Needs
+ * cumf_plan_set_gather_rows; f = 64..79 or 96..111 with f % 16 in {0, 4}.
  *   cumf_set_presplit(mode)   CUMF_PRESPLIT_AUTO (default): tables whose planes take at most CUMF_ALS_PRESPLIT_MB (64) MB;
- *                             CUMF_PRESPLIT_OFF / CUMF_PRESPLIT_ON: never / whenever the shape allows.  Also the
- *                             environment variable CUMF_ALS_PRESPLIT=0|1 read at the first half-iteration.
+ *                             CUMF_PRESPLIT_OFF / CUMF_PRESPLIT_ON: never / whenever the shape allows;
+ *                             CUMF_PRESPLIT_VERIFY: like ON, with the last block unpacked -- the same operands in the same
+ *                             MFMA slots as the in-kernel split, BIT-IDENTICAL results (what the tests compare).  Also the
+ *                             environment variable CUMF_ALS_PRESPLIT=0|1|2 read at the first half-iteration.
  *   cumf_presplit_table       writes the planes of a rows x f table (device pointers; rows of cumf_presplit_pitch(f) bytes:
  *                             [h: 16 FB bf16][m][l][strip of f % 16 features: h, m, l, 8 zero bytes], FB = f / 16); what the
  *                             fused calls do internally -- exported so that callers and tests can check the planes.
  */
-enum { CUMF_PRESPLIT_AUTO = -1, CUMF_PRESPLIT_OFF = 0, CUMF_PRESPLIT_ON = 1 };
+enum { CUMF_PRESPLIT_AUTO = -1, CUMF_PRESPLIT_OFF = 0, CUMF_PRESPLIT_ON = 1, CUMF_PRESPLIT_VERIFY = 2 };
 int cumf_set_presplit(int mode);
 int cumf_get_presplit(void);
 long cumf_presplit_pitch(int f);

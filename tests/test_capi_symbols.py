@@ -93,6 +93,92 @@ def test_widen_rowptr_unwraps_4_byte_row_pointers(alslib):
     assert rc != 0   # does not end at nnz
 
 
+def _wave_object_disassemblies():
+    """(object name, disassembly text) of every wave-kernel object of the product build (gfx950 code object inside the
+    host object), built if absent."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    import pytest
+
+    from cumf_als_amd import lib
+
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")]
+    if not all(os.path.exists(t) for t in tools):
+        pytest.skip("ROCm LLVM binutils not present")
+    objs = sorted(o for o in glob.glob(os.path.join(lib.CSRC, "als_wave_[wl]*.o")) if "_ablate" not in o)
+    if not objs:
+        lib.build()
+        objs = sorted(o for o in glob.glob(os.path.join(lib.CSRC, "als_wave_[wl]*.o")) if "_ablate" not in o)
+    assert len(objs) >= 18, objs
+    tmp = tempfile.mkdtemp()
+    try:
+        for o in objs:
+            fat, co = os.path.join(tmp, "x.fatbin"), os.path.join(tmp, "x.co")
+            subprocess.run([tools[0], "-O", "binary", "--only-section=.hip_fatbin", o, fat], check=True)
+            subprocess.run([tools[1], "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                            f"--output={co}"], check=True, capture_output=True)
+            yield os.path.basename(o), subprocess.run([tools[2], "-d", co], check=True, capture_output=True, text=True).stdout
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def _vregs(tok):
+    """'v12' -> {12}; 'v[10:13]' -> {10..13}; anything else -> empty."""
+    m = re.fullmatch(r"v(\d+)", tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    return set(range(int(m.group(1)), int(m.group(2)) + 1)) if m else set()
+
+
+def test_k32_mfma_operand_wait_states_in_wave_kernels():
+    """a VALU write of an A / B operand register needs wait states in front of
+    v_mfma_f32_16x16x32_bf16 -- two for dword 0 / 1 of the operand quad, one for dword 2 / 3 (measured:
+    tools/probes/mfma_k32_hazard_probe.hip, profiles/r05/mfma_k32_operand_hazard.txt; hipcc missed it once in a sibling
+    kernel).  The Gram stage doubles the h plane (v_pk_add_u16) right in front of the diagonal tiles' MFMAs, so the rule is
+    checked in the shipped ISA of every wave-kernel object instead of trusted to the compiler's hazard recogniser:
+    a build with fewer wait states fails here."""
+    bad = []
+    n_mfma = 0
+    for name, dis in _wave_object_disassemblies():
+        window = []  # (destination registers of a VALU write | None, wait states the instruction itself supplies)
+        for ln in dis.splitlines():
+            parts = ln.split("//")[0].strip().split(None, 1)
+            if not parts or parts[0].endswith(":") or not re.match(r"[a-z]", parts[0]):
+                if ln.rstrip().endswith(">:"):
+                    window = []  # a new function
+                continue
+            op = parts[0]
+            args = [a.strip() for a in parts[1].split(",")] if len(parts) > 1 else []
+            if op.startswith("v_mfma_f32_16x16x32_bf16") and len(args) >= 3:
+                n_mfma += 1
+                a_regs, b_regs = sorted(_vregs(args[1])), sorted(_vregs(args[2]))
+                states = 0
+                for dst, own in reversed(window):
+                    if dst:
+                        for quad in (a_regs, b_regs):
+                            for r in dst & set(quad):
+                                need = 2 if quad.index(r) < 2 else 1
+                                if states < need:
+                                    bad.append((name, ln.strip()[:60], f"v{r}", states, need))
+                    states += own
+                    if states >= 2:
+                        break
+            if op == "s_nop":
+                window.append((None, int(args[0], 0) + 1 if args else 1))
+            elif op.startswith("v_") and "mfma" not in op and args:
+                window.append((_vregs(args[0]), 1))
+            else:
+                window.append((None, 1))
+            window = window[-4:]
+    assert n_mfma > 5000, n_mfma   # the scan saw the kernels
+    assert not bad, bad[:10]
+
+
 def test_no_packed_fp32_math_in_wave_kernels():
     """a round-3 build whose compiler had formed v_pk_fma_f32 in the CG of the wave kernels returned wrong
     mat-vecs, and only -fno-slp-vectorize keeps packed fp32 math out.  Round 4 showed the instruction itself to be clean

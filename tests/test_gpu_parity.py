@@ -1029,12 +1029,20 @@ def test_presplit_planes_are_the_in_kernel_split(alslib, f):
 @pytest.mark.parametrize("f", [100, 64, 96, 68])
 def test_presplit_is_bit_identical(alslib, f, solver):
     """The fused half-iteration from the pre-split table (16-byte LDS-DMA + transposing LDS reads) against the same call with
-    the in-kernel split: same operands in the same MFMA K slots, so the factors -- and the fused train SSE bins -- must be
-    BIT-IDENTICAL, over rows of 0, 1, 31, 32, 33, ... ratings, a chunked row of 9 000 and 150 random ones."""
+    the in-kernel split, over rows of 0, 1, 31, 32, 33, ... ratings, a chunked row of 9 000 and 150 random ones: the
+    verification form (cumf_set_presplit(CUMF_PRESPLIT_VERIFY): the same operands in the same MFMA K slots) must give the
+    factors -- and the fused train SSE bins -- BIT FOR BIT; the production form (last block packed) the same error class."""
     _need_gpu()
     o = _presplit_tool().check_fused(f, solver)
-    assert o["kernel_on"].split(",")[3].strip() == "2" and o["kernel_off"].split(",")[3].strip() == "0", o
+    arith = lambda k: o[k].split(",")[3].strip()
+    assert (arith("kernel_off"), arith("kernel_verify"), arith("kernel_on")) == ("0", "2", "3"), o
     assert o["bit_identical"] and o["sse_bins_identical"] in (True, None), o
+    # the production form multiplies the last feature block as ONE packed operand (three products instead of six, all nine
+    # plane products kept): the error class of the in-kernel split, not its bits -- 2e-5 of the factors' scale here (measured
+    # 1e-7 .. 3e-6), the fused train SSE to 1e-6; the oracle-level bounds are those of test_fused_half_iteration etc., which
+    # run this form wherever the table is small
+    assert o["packed_nan_pattern_equal"] and o["packed_max_rel_diff"] < 2e-5, o
+    assert o["packed_sse_rel_diff"] is None or o["packed_sse_rel_diff"] < 1e-6, o
 
 
 def test_presplit_auto_follows_the_table_size(alslib, monkeypatch):
@@ -1048,7 +1056,7 @@ def test_presplit_auto_follows_the_table_size(alslib, monkeypatch):
     lens = rng.randint(1, 200, 64)
     indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     plan = als.Plan(indptr, f)
-    for n_rows, want in ((5000, "2"), (200000, "0")):   # 3 MB / 122 MB of planes
+    for n_rows, want in ((5000, "3"), (200000, "0")):   # 3 MB / 122 MB of planes
         idx = torch.from_numpy(rng.randint(0, n_rows, int(indptr[-1])).astype(np.int32)).cuda()
         val = torch.ones(int(indptr[-1]), device="cuda")
         table = torch.rand((n_rows, f), device="cuda")
