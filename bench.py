@@ -488,14 +488,16 @@ def hugewiki_leg_guarded(a, als, datagen, dev, world, rank, backend):
     """`hugewiki_leg` so that no rank's failure takes the line down: the local part (slab generation, engine construction:
     no collective) runs under try / except on every rank and the ranks agree on the outcome with ONE all-reduce (MIN) before
     the first collective of the leg; the collective part runs under try / except too (symmetric failures: an RCCL error)
-    and under the LineGuard's deadline (asymmetric ones: a hang).  CUMF_BENCH_FAIL_LEG=<rank> injects a failure on that
-    rank (tests/test_dist_gpu.py)."""
+    and under the LineGuard's deadline (asymmetric ones: a hang).  CUMF_BENCH_FAIL_LEG=<rank> / hang<rank> injects a failure /
+    a hang on that rank (tests/test_dist_gpu.py)."""
     import torch.distributed as dist
 
     state, err = None, None
     try:
         if os.environ.get("CUMF_BENCH_FAIL_LEG") == str(rank):
             raise RuntimeError(f"injected failure on rank {rank} (CUMF_BENCH_FAIL_LEG)")
+        if os.environ.get("CUMF_BENCH_FAIL_LEG") == f"hang{rank}":  # this rank never reaches the leg's collectives
+            time.sleep(1e6)
         state = hugewiki_prepare(a, datagen, dev, world, rank)
     except BaseException as e:  # noqa: BLE001 -- OOM included: the line matters more than the leg
         err = f"rank {rank}: {type(e).__name__}: {e}"

@@ -58,6 +58,9 @@ typedef __attribute__((address_space(3))) float* lds_float_ptr;  // LDS pointer 
 #ifndef CUMF_WAVE_NB
 #error "compile with -DCUMF_WAVE_NB=<feature blocks>"
 #endif
+#ifndef CUMF_ABLATE_STAGE
+#define CUMF_ABLATE_STAGE 0
+#endif
 
 // feature-block counts whose kernels also exist on the pre-split table (kArithPre): f = 96 .. 111 and f = 64 .. 79 -- the
 // headline f = 100 and BASELINE configs[4]'s f = 64 (presplit_nb_ok in als_internal.h is the host's copy of this list)
@@ -592,12 +595,21 @@ struct PreGather {
   lds_tr_ptr tr_last[2];   // ... of the last block, per quad u
   unsigned pitch;
   int len, q, lane;
+#if CUMF_ABLATE_STAGE
+  int dbg;
+#endif
   bool dma_active, sp;
 
   __device__ __forceinline__ void init(const KernelArgs& a, int f, long long begin, int len_, int lane_, float* smem) {
     lane = lane_;
     len = len_;
     pitch = a.pre_pitch;
+#if CUMF_ABLATE
+    if (a.dbg & 8) pitch = 0u;  // profiling build: 8 = every gather hits row 0
+#endif
+#if CUMF_ABLATE_STAGE
+    dbg = a.dbg;
+#endif
     sp = ((f & 15) >> 2) != 0;
     q = lane / G::LP;
     const int piece = lane % G::LP;
@@ -707,8 +719,30 @@ struct PreGather {
   static __device__ __forceinline__ u32x2 tr_read(lds_tr_ptr p, int byte_off) {
     return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)((lds_byte_ptr)p + byte_off)));
   }
+  // the planes of the full blocks B0 .. B1 - 1
+  template <int B0, int B1, class PL>
+  __device__ __forceinline__ void read_blocks(PL& P) const {
+    static_for<B1 - B0>([&](auto bc) {
+      constexpr int B = B0 + decltype(bc)::value;
+      static_for<2>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        const u32x2 vh = tr_read(tr_main, (3 * u + 0) * G::CS + 32 * B);
+        const u32x2 vm = tr_read(tr_main, (3 * u + 1) * G::CS + 32 * B);
+        const u32x2 vl = tr_read(tr_main, (3 * u + 2) * G::CS + 32 * B);
+        P.h[B][2 * u] = vh[0], P.h[B][2 * u + 1] = vh[1];
+        P.m[B][2 * u] = vm[0], P.m[B][2 * u + 1] = vm[1];
+        P.l[B][2 * u] = vl[0], P.l[B][2 * u + 1] = vl[1];
+      });
+    });
+  }
+  template <class PL>
+  __device__ __forceinline__ void read_pk(PL& P) const {  // the packed last block (kArithPrePk)
+    const u32x2 v0 = tr_read(tr_last[0], 0), v1 = tr_read(tr_last[1], 0);
+    P.pk = u32x4{v0[0], v0[1], v1[0], v1[1]};
+  }
   template <class PL>
   __device__ __forceinline__ void read(PL& P) const {
+    if constexpr (PK) read_pk(P);
     static_for<G::FB>([&](auto bc) {
       constexpr int B = decltype(bc)::value;
       static_for<2>([&](auto uc) {
@@ -722,10 +756,7 @@ struct PreGather {
       });
     });
     // the last block (no generic lambda here: the form not taken must be discarded, not just skipped)
-    if constexpr (PK) {
-      const u32x2 v0 = tr_read(tr_last[0], 0), v1 = tr_read(tr_last[1], 0);
-      P.pk = u32x4{v0[0], v0[1], v1[0], v1[1]};
-    } else {
+    if constexpr (!PK) {
       constexpr int B = G::FB;
       const u32x2 h0 = tr_read(tr_last[0], 0), m0 = tr_read(tr_last[0], 8), l0 = tr_read(tr_last[0], 16);
       const u32x2 h1 = tr_read(tr_last[1], 0), m1 = tr_read(tr_last[1], 8), l1 = tr_read(tr_last[1], 16);
@@ -738,46 +769,58 @@ struct PreGather {
 
 // MFMA schedule of kArithPrePk: as make_gram_sched on the full blocks (six products, four on their diagonal tiles); the last
 // block column three products against the packed operand (kPL, kPM, kPH: small terms first), its diagonal tile one (kPP).
+// In TWO groups: the tiles among the first HB feature blocks (+ their strip tiles) first -- their operands are the first
+// transposing reads to return, so these MFMAs run while the reads of the other blocks are still in flight (the waits are
+// the compiler's, per operand); the LDS-DMA of the next stage is issued between the groups, behind the last read.  The
+// order of the products of any ONE tile is the same in both groups and as in make_gram_sched.
 enum { kPL = 8, kPM = 9, kPH = 10, kPP = 11 };
 template <int NB>
 struct GramSchedPk {
   static constexpr int FB = NB - 1, NTF = FB * (FB + 1) / 2;
   static constexpr int N = 6 * NTF - 2 * FB + 3 * FB + 1;
+  static constexpr int HB = FB >= 4 ? FB / 2 : FB;  // blocks of the first group (all of them for small systems)
   int tile[N], kind[N];
+  int n1;  // MFMAs of the first group
 };
 template <int NB>
 __host__ __device__ constexpr GramSchedPk<NB> make_gram_sched_pk() {
-  constexpr int FB = NB - 1, NTF = FB * (FB + 1) / 2, NOFF = NTF - FB;
+  constexpr int FB = NB - 1, HB = GramSchedPk<NB>::HB;
   GramSchedPk<NB> s{};
-  int off[NOFF > 0 ? NOFF : 1] = {}, dg[FB > 0 ? FB : 1] = {}, st[FB > 0 ? FB : 1] = {};
-  int no = 0;
-  for (int I = 0; I < FB; ++I) {
-    dg[I] = tile_of<NB>(I, I);
-    st[I] = tile_of<NB>(I, NB - 1);
-    for (int J = I + 1; J < FB; ++J) off[no++] = tile_of<NB>(I, J);
-  }
   int n = 0;
-  for (int k = 0; k < NOFF; ++k) { s.tile[n] = off[k]; s.kind[n++] = kLH; }
-  for (int I = 0; I < FB; ++I) { s.tile[n] = st[I]; s.kind[n++] = kPL; }
-  for (int k = 0; k < NOFF; ++k) { s.tile[n] = off[k]; s.kind[n++] = kHL; }
-  int used = 0;  // separators inside the diagonal triples: off-diagonal mm products, then the strip's m products
-  for (int I = 0; I < FB; ++I) {
-    s.tile[n] = dg[I]; s.kind[n++] = kD2L;
-    if (used < NOFF) { s.tile[n] = off[used++]; s.kind[n++] = kMM; }
-    else { s.tile[n] = st[used - NOFF]; s.kind[n++] = kPM; ++used; }
-    s.tile[n] = dg[I]; s.kind[n++] = kD2M;
+  for (int grp = 0; grp < 2; ++grp) {
+    // tiles of this group: (I, J) with max(I, J) < HB (group 0) or >= HB (group 1); strip tile I with I < HB / >= HB
+    auto in = [&](int I, int J) { return ((I > J ? I : J) < HB) == (grp == 0); };
+    int off[FB * FB + 1] = {}, dg[FB + 1] = {}, st[FB + 1] = {};
+    int no = 0, nd = 0, ns = 0;
+    for (int I = 0; I < FB; ++I) {
+      if (in(I, I)) { dg[nd++] = I; st[ns++] = tile_of<NB>(I, NB - 1); }
+      for (int J = I + 1; J < FB; ++J)
+        if (in(I, J)) off[no++] = tile_of<NB>(I, J);
+    }
+    for (int k = 0; k < no; ++k) { s.tile[n] = off[k]; s.kind[n++] = kLH; }
+    for (int k = 0; k < ns; ++k) { s.tile[n] = st[k]; s.kind[n++] = kPL; }
+    for (int k = 0; k < no; ++k) { s.tile[n] = off[k]; s.kind[n++] = kHL; }
+    int used = 0;  // separators inside the diagonal triples: off-diagonal mm products, then the strip's m products
+    for (int k = 0; k < nd; ++k) {
+      s.tile[n] = tile_of<NB>(dg[k], dg[k]); s.kind[n++] = kD2L;
+      if (used < no) { s.tile[n] = off[used]; s.kind[n++] = kMM; }
+      else if (used - no < ns) { s.tile[n] = st[used - no]; s.kind[n++] = kPM; }
+      ++used;
+      s.tile[n] = tile_of<NB>(dg[k], dg[k]); s.kind[n++] = kD2M;
+    }
+    for (int k = used; k < no; ++k) { s.tile[n] = off[k]; s.kind[n++] = kMM; }
+    for (int k = (used > no ? used - no : 0); k < ns; ++k) { s.tile[n] = st[k]; s.kind[n++] = kPM; }
+    for (int k = 0; k < nd; ++k) { s.tile[n] = tile_of<NB>(dg[k], dg[k]); s.kind[n++] = kMM; }
+    for (int k = 0; k < no; ++k) { s.tile[n] = off[k]; s.kind[n++] = kMH; }
+    for (int k = 0; k < no; ++k) { s.tile[n] = off[k]; s.kind[n++] = kHM; }
+    for (int k = 0; k < ns; ++k) { s.tile[n] = st[k]; s.kind[n++] = kPH; }
+    for (int k = 0; k < nd; ++k) { s.tile[n] = tile_of<NB>(dg[k], dg[k]); s.kind[n++] = kHH; }
+    for (int k = 0; k < no; ++k) { s.tile[n] = off[k]; s.kind[n++] = kHH; }
+    if (grp == 0) {
+      s.tile[n] = tile_of<NB>(NB - 1, NB - 1); s.kind[n++] = kPP;
+      s.n1 = n;
+    }
   }
-  for (int k = used; k < NOFF; ++k) { s.tile[n] = off[k]; s.kind[n++] = kMM; }
-  for (int k = (used > NOFF ? used - NOFF : 0); k < FB; ++k) { s.tile[n] = st[k]; s.kind[n++] = kPM; }
-  for (int I = 0; I < FB; ++I) { s.tile[n] = dg[I]; s.kind[n++] = kMM; }
-  for (int k = 0; k < NOFF; ++k) { s.tile[n] = off[k]; s.kind[n++] = kMH; }
-  for (int k = 0; k < NOFF; ++k) { s.tile[n] = off[k]; s.kind[n++] = kHM; }
-  for (int I = 0; I < FB; ++I) { s.tile[n] = st[I]; s.kind[n++] = kPH; }
-  for (int I = 0; I < FB; ++I) {
-    s.tile[n] = dg[I]; s.kind[n++] = kHH;
-    for (int J = I + 1; J < FB; ++J) { s.tile[n] = tile_of<NB>(I, J); s.kind[n++] = kHH; }
-  }
-  s.tile[n] = tile_of<NB>(NB - 1, NB - 1); s.kind[n++] = kPP;
   return s;
 }
 template <int NB, int N>
@@ -878,10 +921,62 @@ __device__ __forceinline__ void stage_step_pre(const PreGather<NB, PK>& wg, PL& 
       wg.template load_idx<false>(R, s_load);
   }
   u32x4 h2[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
-  if constexpr (PK)
-    static_for<GramSchedPk<NB>::N>([&](auto nc) { gram_mfma_sched_pk<NB, decltype(nc)::value>(P, acc, h2); });
-  else
-    static_for<GramSched<NB>::N>([&](auto nc) { gram_mfma_sched<NB, decltype(nc)::value>(P, acc, h2); });
+  static_for<GramSched<NB>::N>([&](auto nc) { gram_mfma_sched<NB, decltype(nc)::value>(P, acc, h2); });
+}
+
+// kArithPrePk: the same step with the MFMAs in two groups around the prefetch (make_gram_sched_pk) -- the first group needs
+// only the operands of the first blocks and runs under the transposing reads of the others.
+template <int NB, int KIND>
+__device__ __forceinline__ void stage_step_pk(const PreGather<NB, true>& wg, Planes<NB, kArithPrePk>& P, PreStage<NB>& R,
+                                              float* smem, f32x4 (&acc)[NB * (NB + 1) / 2], int s_next, int s_load) {
+  constexpr GramSchedPk<NB> S = make_gram_sched_pk<NB>();
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the chunks of this stage have landed, R is complete
+  wg.put_rating(R, smem);
+  constexpr int FB = NB - 1, HB = GramSchedPk<NB>::HB, kLate = 6 * (FB - HB);  // transposing reads of the second group's blocks
+  u32x4 h2[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+#if CUMF_ABLATE_STAGE  // one-off timing builds only (tools/wave_variants.sh EXTRA="-DCUMF_ABLATE=1 -DCUMF_ABLATE_STAGE=1"): a
+  // switch inside the stage changes its scheduling regions, so the profiling build proper has none here
+  if (wg.dbg & 32) {  // 32 = no transposing reads (the operands keep the first stage's values)
+    static_for<S.n1>([&](auto nc) { gram_mfma_sched_pk<NB, decltype(nc)::value>(P, acc, h2); });
+  } else
+#endif
+  {
+    wg.read_pk(P);
+    wg.template read_blocks<0, HB>(P);
+    __builtin_amdgcn_sched_barrier(0);
+    // One region: the reads of the other blocks go out ONE BEHIND EACH of the first MFMAs (at most 16 LDS operations are in
+    // flight per wave -- a burst of reads in front of the MFMAs would hold the wave until all but 16 have returned)
+    wg.template read_blocks<HB, FB>(P);
+    static_for<S.n1>([&](auto nc) { gram_mfma_sched_pk<NB, decltype(nc)::value>(P, acc, h2); });
+    static_for<(kLate < S.n1 ? kLate : S.n1)>([&](auto) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one LDS read
+    });
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): every operand is in registers, the image is free
+  if constexpr (KIND == kStepFull) {
+#if CUMF_ABLATE_STAGE
+    if (!(wg.dbg & 16))  // 16 = no LDS-DMA in the steady state
+#endif
+    wg.template dma_issue<true>(R, smem, s_next);
+    wg.template load_idx<true>(R, s_load);
+    wg.template load_rv<true>(R, s_next);
+  } else if constexpr (KIND == kStepPartial) {
+    const int nfull = wg.len / kWaveStage, nst = (wg.len + kWaveStage - 1) / kWaveStage;
+    if (s_next < nfull) {
+      wg.template dma_issue<true>(R, smem, s_next);
+      wg.template load_rv<true>(R, s_next);
+    } else {
+      wg.template dma_issue<false>(R, smem, s_next);
+      wg.template load_rv<false>(R, s_next);
+    }
+    if (s_load < nfull)
+      wg.template load_idx<true>(R, s_load);
+    else if (s_load < nst)
+      wg.template load_idx<false>(R, s_load);
+  }
+  static_for<GramSchedPk<NB>::N - S.n1>([&](auto nc) { gram_mfma_sched_pk<NB, S.n1 + decltype(nc)::value>(P, acc, h2); });
 }
 
 // ----------------------------------------------------------------------------------
@@ -1579,10 +1674,16 @@ __global__ __launch_bounds__(64, CUMF_WAVE_MIN_WAVES) void als_wave_kernel(const
       wg.template load_rv<false>(R, 0);
       wg.template load_idx<false>(R, clamp(1));
       int s = 0;
-      for (; s + 2 < nfull; ++s) stage_step_pre<NB, kStepFull, PK>(wg, P, R, smem, acc, s + 1, s + 2);
-      for (; s + 1 < nst; ++s) stage_step_pre<NB, kStepPartial, PK>(wg, P, R, smem, acc, s + 1, s + 2);
-      stage_step_pre<NB, kStepLast, PK>(wg, P, R, smem, acc, 0, 0);
-      if constexpr (PK) wave_fold_strip<NB>(acc, wg.sp, lane);
+      if constexpr (PK) {
+        for (; s + 2 < nfull; ++s) stage_step_pk<NB, kStepFull>(wg, P, R, smem, acc, s + 1, s + 2);
+        for (; s + 1 < nst; ++s) stage_step_pk<NB, kStepPartial>(wg, P, R, smem, acc, s + 1, s + 2);
+        stage_step_pk<NB, kStepLast>(wg, P, R, smem, acc, 0, 0);
+        wave_fold_strip<NB>(acc, wg.sp, lane);
+      } else {
+        for (; s + 2 < nfull; ++s) stage_step_pre<NB, kStepFull, PK>(wg, P, R, smem, acc, s + 1, s + 2);
+        for (; s + 1 < nst; ++s) stage_step_pre<NB, kStepPartial, PK>(wg, P, R, smem, acc, s + 1, s + 2);
+        stage_step_pre<NB, kStepLast, PK>(wg, P, R, smem, acc, 0, 0);
+      }
     } else {
     WaveGather<NB> wg;
     wg.init(a, f, begin, len, lane);

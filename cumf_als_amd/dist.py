@@ -419,6 +419,7 @@ class DistALS:
         dev, f, w = self.thetaT.device, self.f, self.world
         self._gx = self._gt = None
         self._sse_const = None  # (sum r^2 over all ranks, lambda * n_v per Theta column): built on first use
+        self._sum_r2 = None     # gather scheme: sum r^2 over all ranks (near-perfect-fit rule of the fused train SSE)
         self._fused_sse_ok = {}  # solver -> every RANK's Theta plans deliver the fused train SSE (decided collectively, once)
         if self.scheme == "gather":
             self._gx = SlabGather(self.xb, f, torch.float32, dev, self.group)
@@ -591,6 +592,28 @@ class DistALS:
             self._sse_const = (float(s.item()), reg.float().to(self.XT.device))
         return self._sse_const
 
+    def _sum_r2_all_ranks(self) -> float:
+        """Sum of r^2 over the training ratings of ALL ranks (a constant of the data, all-reduced once): the yardstick of
+        the near-perfect-fit rule below.  `reduce` scheme: part of `_train_sse_constants`; `gather` scheme: over this
+        rank's Theta slab of the CSC."""
+        if self.scheme == "reduce":
+            return self._train_sse_constants()[0]
+        if getattr(self, "_sum_r2", None) is None:
+            s = torch.tensor([float((self.t_val.double() ** 2).sum().item())], dtype=torch.float64)
+            if dist.is_initialized() and self.world > 1:
+                if dist.get_backend() == "nccl":
+                    s = s.to(self.thetaT.device)
+                dist.all_reduce(s, group=self.group)
+            self._sum_r2 = float(s.item())
+        return self._sum_r2
+
+    def _trusted_sse(self, sse: float):
+        """The train SSE out of the Theta update is an fp32 identity per column (absolute error ~1e-7 of the column's
+        sum r^2): on a near-perfect fit it is cancellation noise and may even come out negative.  The rule of
+        doALS (als_driver.cpp): below 1e-3 of sum r^2 the value is not reported -- None, and the caller evaluates
+        `slab_sse` directly.  `sse` is already all-reduced, so every rank decides alike."""
+        return sse if sse >= 1e-3 * self._sum_r2_all_ranks() else None
+
     def _fused_sse_everywhere(self) -> bool:
         """`gather` scheme: can the fused kernels of EVERY rank deliver the train SSE of their Theta slab?  Availability
         depends on the plan (a slab with one chunked heavy column is refused for LU below f = 96 or CG at f = 112..128),
@@ -612,7 +635,8 @@ class DistALS:
     def update_theta(self, train_sse: bool = False):
         """update Theta.  train_sse=True: also return sum over ALL ranks of (r - x_u . theta_v)^2 over the training ratings
         with the new Theta -- from the solved systems themselves, no pass over the ratings (None when the ops or the plans
-        cannot deliver it: the caller then runs `slab_sse`)."""
+        cannot deliver it, or when the fit is so close that the identity is cancellation noise -- `_trusted_sse`: the
+        caller then runs `slab_sse`)."""
         if self.scheme == "gather":
             bins = None
             if train_sse:
@@ -629,7 +653,7 @@ class DistALS:
                 if dist.get_backend() != "nccl":
                     t = t.cpu()
                 dist.all_reduce(t, group=self.group)
-            return float(t.item())
+            return self._trusted_sse(float(t.item()))
         quad = getattr(self.ops, "quad_terms", None) if train_sse else None
         terms = None
         if quad is not None:
@@ -686,7 +710,7 @@ class DistALS:
             if dist.get_backend() != "nccl":
                 t = t.cpu()
             dist.all_reduce(t, group=self.group)
-        return s_total - float(t.item())
+        return self._trusted_sse(s_total - float(t.item()))
 
     # -- RMSE (hugewiki.cu:2750-2862: per-GPU SSE over its slab, summed) -------------------------
     def slab_sse(self, val: torch.Tensor, row_local: torch.Tensor, col: torch.Tensor) -> float:

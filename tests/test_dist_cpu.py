@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: world_size 2, gloo, one process per rank (torch.multiprocessing spawn).
+"""N > 1 path on CPU: world_size 2 (and 3, 4, 8: round 6), gloo, one process per rank (torch.multiprocessing spawn).
 
 Checks that both partitionings of cumf_als_amd.dist reproduce the single-process result:
   * "gather": row slabs of X and Theta + one all-gather per half-iteration -- factors are
@@ -123,17 +123,17 @@ def test_cost_balanced_slabs():
     assert pb[0, 0] == 0 and pb[0, -1] == by_cost[1] == pb[1, 0] and pb[1, -1] == len(lens)
 
 
-@pytest.mark.parametrize("scheme,solver", [("gather", "cg"), ("gather", "lu"), ("reduce", "lu"), ("reduce", "cg")])
-def test_world2_matches_single_process(oracle, scheme, solver):
+def _matches_single_process(oracle, world, scheme, solver, m, n, theta_batch):
     from cumf_als_amd import datagen
 
-    m, n, f, lam, iters = 60, 50, 10, 0.05, 3
+    f, lam, iters = 10, 0.05, 3
     r = datagen.synth_ratings(m, n, 2400, 300, seed=11, row_alpha=1.1)
     d = {k: v for k, v in r.numpy().items()}
     theta0 = (0.2 * np.random.RandomState(0).random_sample((n, f))).astype(np.float32)
     th_ref, x_ref = theta0.copy(), np.zeros((m, f), np.float32)
     oracle.do_als(d, th_ref, x_ref, m, n, f, lam, iters, solver=solver)
-    outs = _run(2, scheme, solver, d, m, n, f, lam, iters, 2 if scheme == "reduce" else 1, theta0)
+    outs = _run(world, scheme, solver, d, m, n, f, lam, iters, theta_batch if scheme == "reduce" else 1, theta0)
+    assert [o[0] for o in outs] == list(range(world))
     for rank, th, x in outs:
         if scheme == "gather":
             np.testing.assert_array_equal(th, th_ref)
@@ -149,8 +149,25 @@ def test_world2_matches_single_process(oracle, scheme, solver):
             sse_ref = oracle.sse(d["csr_data"], d["coo_row"], d["csr_indices"], th_ref, x_ref, r.nnz, f)
             assert abs((sse / r.nnz) ** 0.5 - (sse_ref / r.nnz) ** 0.5) <= 1e-4
     # every rank ends with the same replicas
-    np.testing.assert_array_equal(outs[0][1], outs[1][1])
-    np.testing.assert_array_equal(outs[0][2], outs[1][2])
+    for o in outs[1:]:
+        np.testing.assert_array_equal(outs[0][1], o[1])
+        np.testing.assert_array_equal(outs[0][2], o[2])
+
+
+@pytest.mark.parametrize("scheme,solver", [("gather", "cg"), ("gather", "lu"), ("reduce", "lu"), ("reduce", "cg")])
+def test_world2_matches_single_process(oracle, scheme, solver):
+    _matches_single_process(oracle, 2, scheme, solver, 60, 50, 2)
+
+
+@pytest.mark.parametrize("world,scheme,solver,theta_batch", [(3, "gather", "lu", 1), (3, "reduce", "cg", 3), (4, "reduce", "lu", 2),
+                                                             (8, "gather", "cg", 1), (8, "reduce", "lu", 3)])
+def test_world_3_4_8_matches_single_process(oracle, world, scheme, solver, theta_batch):
+    """the arithmetic that only appears above two ranks -- k = ceil(size / world) systems per rank and
+    Theta batch with a short or EMPTY last share (n = 53 columns, THETA_BATCH = 3: batches of 17, 17, 19 over eight ranks
+    give k = 3: the sixth rank holds 2 / 2 / 3 systems... the last ranks none), eight uneven slabs padded to the largest in
+    SlabGather (m = 61 rows), slabs of a handful of rows -- on the CPU with the stand-in ops: `gather` bit-identical to the
+    single-process oracle, `reduce` to rounding."""
+    _matches_single_process(oracle, world, scheme, solver, 61, 53, theta_batch)
 
 
 @pytest.mark.parametrize("solver", ["cg", "lu"])
@@ -186,8 +203,8 @@ def test_hugewiki_runner_from_split_files(tmp_path, solver):
     assert np.abs(outs[0][1] - th0.reshape(n, f)).max() <= 2e-3 * max(1.0, np.abs(th0).max())
 
 
-@pytest.mark.parametrize("solver,theta_batch", [("lu", 1), ("cg", 3)])
-def test_reduce_scheme_train_sse_from_the_reduced_systems(oracle, solver, theta_batch):
+@pytest.mark.parametrize("solver,theta_batch,world", [("lu", 1, 2), ("cg", 3, 2), ("lu", 3, 3), ("cg", 2, 8)])
+def test_reduce_scheme_train_sse_from_the_reduced_systems(oracle, solver, theta_batch, world):
     """Round 4: in the `reduce` scheme the train SSE comes out of the Theta update -- sum r^2 (a constant of the data,
     all-reduced once) minus the all-reduced sum over every rank's systems of 2 t.b - t^T G t -- instead of a pass over
     every rank's ratings (hugewiki.cu:2750-2862).  Two ranks against the direct evaluation on the full factors."""
@@ -201,20 +218,20 @@ def test_reduce_scheme_train_sse_from_the_reduced_systems(oracle, solver, theta_
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=dist_helpers.train_sse_worker,
-                         args=(rk, 2, port, solver, d, m, n, f, lam, theta_batch, theta0, q)) for rk in range(2)]
+                         args=(rk, world, port, solver, d, m, n, f, lam, theta_batch, theta0, q)) for rk in range(world)]
     for p in procs:
         p.start()
-    outs = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    outs = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert outs[0][1] == outs[1][1]                      # the all-reduced value is the same on every rank
+    assert all(o[1] == outs[0][1] for o in outs)         # the all-reduced value is the same on every rank
     direct = oracle.sse(d["csr_data"], d["coo_row"], d["csr_indices"], outs[0][2], outs[0][3], r.nnz, f, dtype=np.float64)
     assert abs(outs[0][1] - direct) <= 2e-5 * direct, (outs[0][1], direct)
 
 
-@pytest.mark.parametrize("unavailable_rank", [-1, 1])
-def test_gather_scheme_train_sse_is_decided_collectively(oracle, unavailable_rank):
+@pytest.mark.parametrize("unavailable_rank,world", [(-1, 2), (1, 2), (2, 4)])
+def test_gather_scheme_train_sse_is_decided_collectively(oracle, unavailable_rank, world):
     """in the `gather` scheme the fused train SSE depends on each rank's own plans.  When only ONE
     rank's plans refuse it, every rank must fall back together (update_theta returns None everywhere) -- a rank that
     skipped the all-reduce of the bins alone would pair its next collective with the others' and hang or sum nonsense."""
@@ -228,19 +245,19 @@ def test_gather_scheme_train_sse_is_decided_collectively(oracle, unavailable_ran
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=dist_helpers.gather_sse_worker,
-                         args=(rk, 2, port, "lu", d, m, n, f, lam, theta0, unavailable_rank, q)) for rk in range(2)]
+                         args=(rk, world, port, "lu", d, m, n, f, lam, theta0, unavailable_rank, q)) for rk in range(world)]
     for p in procs:
         p.start()
-    outs = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    outs = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, fused0, direct0), (_, fused1, direct1) = outs
-    assert direct0 == direct1 and direct0 > 0           # the fall-back's own all-reduce paired up
+    fused, direct = [o[1] for o in outs], [o[2] for o in outs]
+    assert all(v == direct[0] for v in direct) and direct[0] > 0   # the fall-back's own all-reduce paired up
     if unavailable_rank < 0:
-        assert fused0 == fused1 and abs(fused0 - direct0) <= 1e-6 * direct0, (fused0, direct0)
+        assert all(v == fused[0] for v in fused) and abs(fused[0] - direct[0]) <= 1e-6 * direct[0], (fused, direct)
     else:
-        assert fused0 is None and fused1 is None, (fused0, fused1)
+        assert all(v is None for v in fused), fused
 
 
 def test_pipeline_bounds_and_row_map():
@@ -276,10 +293,11 @@ def test_pipeline_bounds_and_row_map():
         assert torch.equal(out, full)
 
 
-def test_world2_pipelined_gather_equals_blocking(monkeypatch):
-    """gather scheme, 2 ranks: the pipelined all-gathers (4 pieces per side: what the default picks for a factor
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_world2_pipelined_gather_equals_blocking(monkeypatch, world):
+    """gather scheme, 2 / 3 / 8 ranks: the pipelined all-gathers (4 pieces per side: what the default picks for a factor
     matrix >= 32 MB) and the blocking ones (CUMF_ALS_PIPE_CHUNKS=1: the default below that) give bit-identical
-    factors."""
+    factors.  Eight ranks x four pieces of 70 / 50 rows: pieces of one or two rows, some empty on some ranks."""
     import numpy as np
 
     from cumf_als_amd import datagen
@@ -291,7 +309,7 @@ def test_world2_pipelined_gather_equals_blocking(monkeypatch):
     res = {}
     for chunks in ("4", "1"):
         monkeypatch.setenv("CUMF_ALS_PIPE_CHUNKS", chunks)  # inherited by the spawned ranks
-        res[chunks] = _run(2, "gather", "lu", d, m, n, f, lam, iters, 1, theta0)
+        res[chunks] = _run(world, "gather", "lu", d, m, n, f, lam, iters, 1, theta0)
     for a, b in zip(res["4"], res["1"]):
         np.testing.assert_array_equal(a[1], b[1])
         np.testing.assert_array_equal(a[2], b[2])
@@ -318,3 +336,19 @@ def test_default_pipeline_pieces_follow_the_gathered_bytes(monkeypatch):
         rowptr = np.arange(rows + 1, dtype=np.int64) * 3
         pipe = eng._make_pipeline(rowptr, rowptr, np.array([0, rows]), 0)
         assert (pipe is None) if want is None else (pipe[0].shape == (1, want + 1)), rows
+
+
+def test_train_sse_near_perfect_fit_is_not_reported():
+    """the train SSE out of the Theta update is an fp32 identity per column; below 1e-3 of sum r^2 it is
+    cancellation noise (possibly negative: a NaN RMSE in the caller).  DistALS then returns None -- as doALS re-evaluates
+    with the RMSE kernel -- and the caller runs `slab_sse`; the yardstick sum r^2 is all-reduced once, the decision is taken
+    on the all-reduced value: the same on every rank."""
+    from cumf_als_amd import dist as cdist
+
+    eng = cdist.DistALS.__new__(cdist.DistALS)
+    eng.scheme, eng.world, eng.group = "gather", 1, None
+    eng.t_val = torch.tensor([3.0, 4.0, 5.0, 1.0, 7.0])          # sum r^2 = 100
+    eng.thetaT = torch.zeros(1)
+    eng._sum_r2 = None
+    assert eng._trusted_sse(5.0) == 5.0 and eng._sum_r2 == 100.0
+    assert eng._trusted_sse(0.05) is None and eng._trusted_sse(-1e-3) is None and eng._trusted_sse(0.1) == 0.1

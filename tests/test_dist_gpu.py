@@ -282,6 +282,42 @@ def test_bench_world2_branch_runs(alslib, args, launch):
         assert len(hw["per_rank"]["x_half_ms"]) == 2 and "configs[3]" in hw["workload"]
 
 
+@pytest.mark.parametrize("fault", ["rank1_raises", "hang"])
+def test_bench_line_survives_a_failing_hugewiki_leg(alslib, fault):
+    """the driver gets one shot at N = 8, and the hugewiki leg runs behind the Netflix line in
+    the same process.  Whatever happens to the leg, the ONE line must come out, with the Netflix numbers intact and
+    `hugewiki: {"error": ...}`:
+      rank1_raises  CUMF_BENCH_FAIL_LEG=1: rank 1 fails while preparing its slab -- the ranks agree on that with one all-reduce
+                    before the leg's first collective and both skip it;
+      hang          CUMF_BENCH_FAIL_LEG=hang1: rank 1 never arrives at that all-reduce -- rank 0's LineGuard prints the line
+                    when its deadline (CUMF_BENCH_LEG_DEADLINE) passes and the ranks leave."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from tests.test_dist_cpu import _free_port
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CUMF_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1",
+               CUMF_BENCH_FAIL_LEG="1" if fault == "rank1_raises" else "hang1", CUMF_BENCH_LEG_DEADLINE="20")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--scale", "0.05", "--no-cpu-baseline", "--scheme", "gather"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (out.stdout[-2000:], out.stderr[-2000:])
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and np.isfinite(line["value"]) and line["ranks"]["n_ranks_seen"] == 2
+    assert "error" in line["hugewiki"] and "value" not in line["hugewiki"], line["hugewiki"]
+    if fault == "rank1_raises":
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert "rank 1" in line["hugewiki"]["error"] or "another rank" in line["hugewiki"]["error"]
+
+
 def test_quadratic_sse_terms_kernel(alslib):
     """cumf_quadratic_sse_terms: sum over a batch of 2 x.b - x^T A x + reg |x|^2 against numpy fp64; systems marked with reg < 0
     (a column without ratings, NaN solution) are skipped, reg == 0 (lambda = 0) is a system like any other."""
