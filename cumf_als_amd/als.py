@@ -455,7 +455,9 @@ class ALSEngine:
         import torch
 
         self.r, self.f, self.lam = r, f, float(lambda_)
-        self.solver, self.cg_iters, self.fused = solver, cg_iters, fused
+        self.solver, self.cg_iters = solver, cg_iters
+        # above the tile kernels' range (f > 207) the reference's unfused data flow runs (cumf_get_hermitian + batched solver)
+        self.fused = bool(fused) and bool(_libmod.load().cumf_fused_available(int(f), _solver_id(solver)))
         self.m, self.n = r.m, r.n
         self.device = r.csr_indices.device
         self.x_plans = self._plans(r.csr_indptr, r.m, x_batch, chunk)

@@ -19,7 +19,8 @@ constexpr int kThreads = 256;   // 4 waves of 64
 constexpr int kStage = 32;      // gathered factor rows per LDS stage
 constexpr int kVecLd = 128;     // pitch of the CG vectors in LDS (fused solve needs f <= 128)
 constexpr int kMaxFusedNB = 9;  // f <= 128  ->  NB = f / 16 + 1 <= 9
-constexpr int kMaxF = 207;      // NB <= 13
+constexpr int kMaxF = 207;      // NB <= 13: the range of the tile kernels (fused paths, MFMA Gram)
+constexpr int kMaxFAny = 512;   // round 6: above kMaxF the reference's unfused data flow on two plain kernels (als_generic.hip)
 constexpr int kMaxWaveNB = 7;   // wave-per-item kernels (als_wave.hip): f <= 111; register budget of one wave
 // two-wave kernel: LU in place up to this NB (CG: always).  Round 5 measured 13 (f = 200 solved in place by the two Gram
 // waves): Theta side 82.4 vs 74.4 ms through the tile buffer (profiles/r05/lu_rows_ab.txt)
@@ -137,11 +138,19 @@ bool wave_batched_path(int f, int mode);
 // unpack = 0: full (batch x f x f) -> packed (batch x f(f+1)/2); unpack = 1: `full` is the packed input,
 // `packed` receives the mirrored full matrices
 hipError_t launch_presplit(const float* src, unsigned* dst, size_t n, int* flag, hipStream_t stream);
+// f > kMaxF (als_generic.hip): the fp32 f x f Gram batch + right-hand sides of the plan's items (whole rows), and the batched
+// unpivoted LU in global memory (A is overwritten with the factors, as cublasSgetrfBatched does)
+hipError_t launch_gram_generic(const KernelArgs& a, long n_items, hipStream_t stream);
+hipError_t launch_lu_global(float* A, const float* b, float* x, long batch, int f, hipStream_t stream);
 // kArithPre: which (f, NB) have kernels on the pre-split bf16x3 table (als_wave.hip: CUMF_WAVE_PRE, presplit_shape_ok), the
 // table's row pitch in bytes, and the kernel that writes it
 __host__ __device__ constexpr bool presplit_supported(int f) {
   return (nb_for_f(f) == 7 || nb_for_f(f) == 5) && ((f & 15) == 0 || (f & 15) == 4);
 }
+// ... and where CUMF_PRESPLIT_AUTO uses them: NB = 7 only.  At NB = 5 (f = 64) the 19 KB stage image costs the third wave per
+// SIMD that the 160-register kernel otherwise gets (10 KB of dword chunks): measured SLOWER, Netflix f = 64 LU Theta side
+// 5.6-5.9 -> 6.4-6.5 ms (profiles/r06/ab_presplit_f64_lu.txt); the kernels stay for CUMF_PRESPLIT_ON and the tests.
+__host__ __device__ constexpr bool presplit_pays(int f) { return presplit_supported(f) && nb_for_f(f) == 7; }
 __host__ __device__ constexpr unsigned presplit_pitch(int f) { return 96u * (f / 16) + (((f & 15) >> 2) ? 32u : 0u); }
 hipError_t launch_presplit3(const float* src, void* dst, long long rows, int f, hipStream_t stream);
 hipError_t launch_pack_upper(const float* full, float* packed, long batch, int f, int unpack, hipStream_t stream);

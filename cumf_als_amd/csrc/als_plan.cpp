@@ -92,8 +92,8 @@ extern "C" int cumf_plan_create(cumf_plan_t** out, const void* rowptr_host, int 
     fprintf(stderr, "cumf_plan_create: invalid arguments\n");
     return (int)hipErrorInvalidValue;
   }
-  if (f <= 0 || f > kMaxF || (f % 2) != 0) {
-    fprintf(stderr, "cumf_plan_create: f = %d unsupported (need even f <= %d)\n", f, kMaxF);
+  if (f <= 0 || f > kMaxFAny || (f % 2) != 0) {
+    fprintf(stderr, "cumf_plan_create: f = %d unsupported (need even f <= %d)\n", f, kMaxFAny);
     return (int)hipErrorInvalidValue;
   }
   auto rp = [&](long i) -> long long {
@@ -104,6 +104,13 @@ extern "C" int cumf_plan_create(cumf_plan_t** out, const void* rowptr_host, int 
   // of one side then cut their heavy rows alike and a batched run stays bit-identical to the unbatched
   // one (als.cu:768-777; tests/test_gpu_fullsize.py)
   if (chunk <= 0) chunk = default_chunk(f, rp(rows) - rp(0));
+  if (f > kMaxF) {
+    // above the tile kernels' range (als_generic.hip) a row is never cut: every item is a whole row, there are no partial tiles
+    long long longest = 0;
+    for (long u = row_begin; u < row_end; ++u) longest = std::max(longest, rp(u + 1) - rp(u));
+    chunk = (int)std::min<long long>(0x7fffffe0LL, std::max<long long>(longest, kStage));
+    chunk = ((chunk + kStage - 1) / kStage) * kStage;
+  }
   chunk = std::max(kStage, (chunk / kStage) * kStage);
 
   std::vector<int> item_row, item_len, item_slot, item_rowlen;
@@ -467,7 +474,7 @@ bool presplit_wanted(const cumf_plan_t* p, int f, int mode) {
   if (pm == CUMF_PRESPLIT_OFF) return false;
   if (gram_mode() != kGramAuto || !wave_path_available(f, mode) || !presplit_supported(f) || p->gather_rows <= 0) return false;
   if (pm == CUMF_PRESPLIT_ON || pm == CUMF_PRESPLIT_VERIFY) return true;
-  return (double)p->gather_rows * presplit_pitch(f) <= cap_mb * 1048576.0;
+  return presplit_pays(f) && (double)p->gather_rows * presplit_pitch(f) <= cap_mb * 1048576.0;
 }
 int pre_words(const cumf_plan_t* p, const float* gather, int f, hipStream_t stream, KernelArgs* a) {
   void* planes = nullptr;
@@ -676,6 +683,14 @@ int get_hermitian_any(const char* who, const cumf_plan_t* p, const int* colidx, 
   a.tt_half = storage == 1;
   a.tt_packed = storage == 2;
   a.rhs = rhs;
+  if (f > kMaxF) {  // above the tile kernels' range: the plain kernel of als_generic.hip, fp32 f x f storage only
+    if (storage != 0) {
+      fprintf(stderr, "%s: f = %d is above the tile kernels' range (%d): only the fp32 f x f batch (cumf_get_hermitian)\n", who, f, kMaxF);
+      return (int)hipErrorInvalidValue;
+    }
+    CUMF_HIP_CHECK(launch_gram_generic(a, p->n_items, static_cast<hipStream_t>(stream)));
+    return 0;
+  }
   PlanLists lists{};
   const bool batched = wave_batched_path(f, kModeMaterialize);
   if (batched) {
@@ -717,15 +732,21 @@ extern "C" int cumf_cg_solve_batched_fp16(const void* A_half, float* x, const fl
 
 extern "C" int cumf_cg_solve_batched(const float* A, float* x, const float* b, long batch, int f, int cg_iters,
                                      void* stream) {
-  if (f <= 0 || f > 256) return (int)hipErrorInvalidValue;
+  if (f <= 0 || f > kMaxFAny) return (int)hipErrorInvalidValue;  // above f = 128: cg_global_kernel, one thread per row of the system
   CUMF_HIP_CHECK(launch_solve_batched(A, b, x, batch, f, kModeCG, cg_iters, static_cast<hipStream_t>(stream)));
   return 0;
 }
 
 extern "C" int cumf_lu_solve_batched(const float* A, const float* b, float* x, long batch, int f, void* stream) {
-  if (f <= 0 || f > 200) {
-    fprintf(stderr, "cumf_lu_solve_batched: f = %d unsupported (LDS-resident system needs f <= 200)\n", f);
+  if (f <= 0 || f > kMaxFAny) {
+    fprintf(stderr, "cumf_lu_solve_batched: f = %d unsupported (f <= %d)\n", f, kMaxFAny);
     return (int)hipErrorInvalidValue;
+  }
+  if (f > 200) {
+    // above the LDS-resident solvers: the elimination in global memory, in the operation order of the unpivoted Doolittle LU +
+    // getrs (als_generic.hip).  A is overwritten with the factors, as cublasSgetrfBatched overwrites it (als.cu:77).
+    CUMF_HIP_CHECK(launch_lu_global(const_cast<float*>(A), b, x, batch, f, static_cast<hipStream_t>(stream)));
+    return 0;
   }
   // CUMF_ALS_LU_EXACT=1: the LDS-resident elimination in the oracle's exact operation order
   // (bit-identical to oracle_lu); default: the register-resident symmetric elimination.
@@ -766,6 +787,7 @@ extern "C" int cumf_quadratic_sse_terms(const float* A, const float* b, const fl
 extern "C" int cumf_check_gather_table(long gather_rows, int f, int solver, int materialize) {
   const int mode = materialize ? kModeMaterialize : (solver == CUMF_SOLVER_LU ? kModeLU : kModeCG);
   if (gather_rows < 0 || f <= 0) return (int)hipErrorInvalidValue;
+  if (f > kMaxF) return 0;  // als_generic.hip: 64-bit gather addresses
   if (wave_path_available(f, mode)) return 0;
   if (nb_for_f(f) > kMaxWaveNB && wave_batched_path(f, mode)) return 0;  // two-waves-per-item Gram: 64-bit addresses too
   const unsigned long long bytes = (unsigned long long)gather_rows * (unsigned long long)f * 4ull;

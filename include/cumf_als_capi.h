@@ -62,7 +62,11 @@ typedef struct cumf_plan cumf_plan_t;
 /* rowptr_host: HOST row pointers of the rows [0, rows] (int32, or int64 when
  * rowptr_is_64 != 0 -- hugewiki.cu:2266 keeps them unsigned for nnz > 2^31).
  * Only rows [row_begin, row_end) are planned (the X_BATCH / THETA_BATCH slices of
- * als.cu:768-777, 881-890).  chunk <= 0 picks the default for f. */
+ * als.cu:768-777, 881-890).  chunk <= 0 picks the default for f.  Any even f <= 512: up to f = 207 the tile kernels
+ * (fused half-iterations, MFMA Gram); above that -- the reference's generic kernel takes every f % 10 == 0,
+ * als.cu:575-659 -- the reference's own data flow on two plain kernels: cumf_get_hermitian (fp32 f x f batch) +
+ * cumf_cg_solve_batched / cumf_lu_solve_batched, which is what doALS then runs (slow, correct, in the reference's
+ * operation order: Gram and LU are bit-identical to a sequential evaluation). */
 int cumf_plan_create(cumf_plan_t** plan, const void* rowptr_host, int rowptr_is_64, long rows,
                      long row_begin, long row_end, int f, int chunk);
 int cumf_plan_destroy(cumf_plan_t* plan);

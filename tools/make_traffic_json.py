@@ -38,7 +38,10 @@ def main():
     # the dominant kernel FAMILY = the Gram kernel with the most fetched bytes over its launches; the two instances of
     # the wave kernel that differ only in the last template argument (WHOLE: the plan has no chunked rows -- the
     # Theta side of the Netflix shape -- or it has -- the X side) are one family
+    # -- and, round 6, in the arithmetic argument in front of it (0: in-kernel split, the X side, whose gather table is
+    # HBM-resident; 3 / 2: the pre-split table of a cache-resident side, the Theta side) -- are one family
     def family(n):
+        n = re.sub(r"(als_wave_kernel<\d+, \d+, \d+), \d+, (true|false)>$", r"\1>", n)
         return re.sub(r",\s*(true|false)>$", ">", n)
 
     by_name = {}
