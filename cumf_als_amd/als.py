@@ -410,6 +410,17 @@ def set_debug_switches(switches: int) -> None:
     _libmod.check(lib.cumf_set_debug_switches(int(switches)), "cumf_set_debug_switches")
 
 
+def debug_cg_histogram(f: int):
+    """Profiling build only, after running with switch 65536: rows by the number of CG iterations they ran before
+    ||r||^2 < 1e-4 ended the loop (cg.cu:195); read and cleared."""
+    lib = _libmod.load()
+    if not hasattr(lib, "cumf_debug_cg_histogram"):
+        raise RuntimeError("the CG histogram exists only in libALS_ablate.so (load it through CUMF_ALS_LIB)")
+    out = (C.c_ulonglong * 16)()
+    _libmod.check(lib.cumf_debug_cg_histogram(int(f), out), "cumf_debug_cg_histogram")
+    return [int(v) for v in out]
+
+
 def last_kernel_name() -> str:
     """Name of the Gram(+solve) kernel the last half-iteration dispatched, as rocprofv3 prints it."""
     buf = C.create_string_buffer(256)

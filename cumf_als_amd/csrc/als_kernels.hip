@@ -879,12 +879,12 @@ __device__ __forceinline__ void reduce_body(float* smem, const KernelArgs& a, in
   finish_row<NB, MODE, W>(acc, smem, a, row, rowlen, lane + 64 * W);
 }
 
-// Round 6: the LU of the largest systems (NB = 13, f = 192 .. 207: 164 registers = three workgroups per CU) is latency- and
+// Round 6: the LU of the largest systems (NB = 12, 13: f = 176 .. 207; 164-168 registers = three workgroups per CU) is latency- and
 // barrier-bound at full clock (61 % of its wave-cycles parked, profiles/r05/f200_lu/pmc_sq.txt): a fourth workgroup per CU is
-// worth more than the 118 registers it spills at 128 -- Netflix f = 200 LU Theta side 74.5 -> 71.4 ms
-// (profiles/r06/ab_r13w4.txt).
+// worth more than the registers it spills at 128 (118 at NB = 13, 28 at NB = 12; NB <= 11 fit anyway) -- Netflix f = 200 LU
+// Theta side 74.5 -> 71.4 ms (profiles/r06/ab_r13w4.txt).
 template <int NB, int MODE>
-__global__ __launch_bounds__(kThreads, (NB == 13 && MODE == kModeLU) ? 4 : 1) void als_reduce_kernel(const KernelArgs a) {
+__global__ __launch_bounds__(kThreads, (NB >= 12 && MODE == kModeLU) ? 4 : 1) void als_reduce_kernel(const KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int mr = blockIdx.x;

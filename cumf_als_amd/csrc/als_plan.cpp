@@ -830,6 +830,23 @@ extern "C" int cumf_set_debug_switches(int switches) {
   g_debug_switches = switches;
   return 0;
 }
+// switch 65536: rows by the number of CG iterations they ran (bins 0 .. 15), read and cleared; f selects the kernels'
+// feature-block count (the profiling build has NB = 5, 7, 13)
+namespace cumf {
+template <int NB>
+hipError_t wave_cg_hist(unsigned long long* out16);
+}
+extern "C" int cumf_debug_cg_histogram(int f, unsigned long long* out16) {
+  if (!out16) return (int)hipErrorInvalidValue;
+  CUMF_HIP_CHECK(hipDeviceSynchronize());
+  switch (nb_for_f(f)) {
+    case 5: CUMF_HIP_CHECK(cumf::wave_cg_hist<5>(out16)); break;
+    case 7: CUMF_HIP_CHECK(cumf::wave_cg_hist<7>(out16)); break;
+    case 13: CUMF_HIP_CHECK(cumf::wave_cg_hist<13>(out16)); break;
+    default: return (int)hipErrorInvalidValue;
+  }
+  return 0;
+}
 #endif
 
 extern "C" int cumf_set_kernel_timing(int enable) {

@@ -71,6 +71,11 @@ constexpr int kZeroFloats = 256; // >= 16 * kMaxWaveNB + 16
 // Zeros that stand in for "no rating here": ratings past the end of an item gather from
 // this row, the pad lanes of the last feature block read it too.
 static __device__ __attribute__((aligned(16))) float g_wave_zeros[kZeroFloats];
+#if CUMF_ABLATE
+// profiling build, switch 65536: how many CG iterations (mat-vecs behind the initial residual) the rows actually ran before
+// ||r||^2 < 1e-4 ended the loop (cg.cu:195) -- bin k = rows that ran k iterations (cumf_debug_cg_histogram)
+static __device__ __attribute__((unused)) unsigned long long g_cg_hist[16];
+#endif
 
 __device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
@@ -1518,7 +1523,13 @@ __device__ __forceinline__ void cg_wave_core(f32x4 (&T)[(NB * (NB + 1) / 2 + NW 
     p[J] = r[J];
   });
   float rsold = dot(r, r);
+#if CUMF_ABLATE
+  int iters_run = 0;
+#endif
   for (int iter = 0; iter < a.cg_iters; ++iter) {
+#if CUMF_ABLATE
+    ++iters_run;
+#endif
     matvec(p, ap);
     const float pap = dot(p, ap);
     const float alpha = rsold / pap;
@@ -1544,6 +1555,9 @@ __device__ __forceinline__ void cg_wave_core(f32x4 (&T)[(NB * (NB + 1) / 2 + NW 
       if (live[J]) xg[16 * J + c] = x[J];
     });
   }
+#if CUMF_ABLATE
+  if ((a.dbg & 65536) && W == 0 && lane == 0) atomicAdd(&g_cg_hist[iters_run < 15 ? iters_run : 15], 1ull);
+#endif
   {
     // fused train SSE: S - x.b - x.r - reg |x|^2 (see wave_tile_ff).  Every wave holds all the vectors (identical bits);
     // the one that owns the last diagonal tile -- entry (f, f) = sum r^2 -- reports.
@@ -2046,6 +2060,19 @@ hipError_t wave_item_launch<CUMF_WAVE_NB>(const KernelArgs& a, int mode, long n_
 }
 
 #endif  // CUMF_WAVE_PART == 0
+
+#if CUMF_ABLATE && CUMF_WAVE_PART == 0
+// profiling build: read (and clear) the CG iteration histogram of this feature-block count's kernels
+template <int NB>
+hipError_t wave_cg_hist(unsigned long long* out16);
+template <>
+hipError_t wave_cg_hist<CUMF_WAVE_NB>(unsigned long long* out16) {
+  hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_cg_hist), 16 * sizeof(unsigned long long));
+  if (e != hipSuccess) return e;
+  const unsigned long long zero[16] = {};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_cg_hist), zero, sizeof(zero));
+}
+#endif
 
 #if CUMF_WAVE_PART == 0 && CUMF_WAVE_NB == 7
 // ----------------------------------------------------------------------------------

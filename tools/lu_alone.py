@@ -24,9 +24,13 @@ def main() -> int:
     ap.add_argument("--raw", type=int, nargs="*", default=[], help="further runs with exactly these switch values")
     ap.add_argument("--only", default="", help="run just this variant (full / gram_only / solve_only): for counter passes, whose "
                     "per-kernel means must not mix the variants; the warm-up iteration then runs with the other solver")
+    ap.add_argument("--shape", default="netflix", help="netflix | hugewiki (the 1/8 row slab one GPU holds)")
     a = ap.parse_args()
-    shp = datagen.SHAPES["netflix"]
-    r = datagen.synth_ratings(shp["m"], shp["n"], shp["nnz"], shp["nnz_test"], seed=0, device="cuda")
+    shp = datagen.SHAPES[a.shape]
+    if a.shape == "hugewiki":
+        r = datagen.synth_ratings(shp["m"] // 8, shp["n"], shp["nnz"] // 8, 4096, seed=0, device="cuda")
+    else:
+        r = datagen.synth_ratings(shp["m"], shp["n"], shp["nnz"], shp["nnz_test"], seed=0, device="cuda")
     eng = als.ALSEngine(r, a.f, shp["lam"], solver=a.solver)
     eng.init_factors()
     als.set_debug_switches(0)
@@ -35,7 +39,7 @@ def main() -> int:
     eng.iterate(1)
     eng.solver = a.solver
     keep_x, keep_t = eng.XT.clone(), eng.thetaT.clone()
-    out = {"library": os.path.basename(os.environ.get("CUMF_ALS_LIB", "libALS.so")), "f": a.f, "solver": a.solver}
+    out = {"library": os.path.basename(os.environ.get("CUMF_ALS_LIB", "libALS.so")), "shape": a.shape, "f": a.f, "solver": a.solver}
     als.set_kernel_timing(True)
     for sw, name in [(0, "full"), (1, "gram_only"), (2, "solve_only")] + [(2 | e, f"solve_only+{e}") for e in a.extra] + [(v, f"switches_{v}") for v in a.raw]:
         if a.only and name != a.only:
