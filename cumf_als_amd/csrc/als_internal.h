@@ -144,14 +144,18 @@ hipError_t launch_gram_generic(const KernelArgs& a, long n_items, hipStream_t st
 hipError_t launch_lu_global(float* A, const float* b, float* x, long batch, int f, hipStream_t stream);
 // kArithPre: which (f, NB) have kernels on the pre-split bf16x3 table (als_wave.hip: CUMF_WAVE_PRE, presplit_shape_ok), the
 // table's row pitch in bytes, and the kernel that writes it
+// One-wave kernels (NB = 5, 7): strip of f % 16 in {0, 4} features; two-wave kernels (NB = 8 .. 13): f % 16 in {0, 4, 8}.
 __host__ __device__ constexpr bool presplit_supported(int f) {
-  return (nb_for_f(f) == 7 || nb_for_f(f) == 5) && ((f & 15) == 0 || (f & 15) == 4);
+  return ((nb_for_f(f) == 7 || nb_for_f(f) == 5) && ((f & 15) == 0 || (f & 15) == 4)) ||
+         (nb_for_f(f) > kMaxWaveNB && nb_for_f(f) <= nb_for_f(kMaxF) && (f & 3) == 0 && (f & 15) <= 8);
 }
 // ... and where CUMF_PRESPLIT_AUTO uses them: NB = 7 only.  At NB = 5 (f = 64) the 19 KB stage image costs the third wave per
 // SIMD that the 160-register kernel otherwise gets (10 KB of dword chunks): measured SLOWER, Netflix f = 64 LU Theta side
 // 5.6-5.9 -> 6.4-6.5 ms (profiles/r06/ab_presplit_f64_lu.txt); the kernels stay for CUMF_PRESPLIT_ON and the tests.
-__host__ __device__ constexpr bool presplit_pays(int f) { return presplit_supported(f) && nb_for_f(f) == 7; }
-__host__ __device__ constexpr unsigned presplit_pitch(int f) { return 96u * (f / 16) + (((f & 15) >> 2) ? 32u : 0u); }
+__host__ __device__ constexpr bool presplit_pays(int f) { return presplit_supported(f) && nb_for_f(f) >= 7; }
+__host__ __device__ constexpr unsigned presplit_pitch(int f) {
+  return 96u * (f / 16) + ((f & 15) ? (nb_for_f(f) > kMaxWaveNB ? 64u : 32u) : 0u);
+}
 hipError_t launch_presplit3(const float* src, void* dst, long long rows, int f, hipStream_t stream);
 hipError_t launch_pack_upper(const float* full, float* packed, long batch, int f, int unpack, hipStream_t stream);
 void set_last_error(int code);  // read (and cleared) by cumf_last_error

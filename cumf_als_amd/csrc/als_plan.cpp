@@ -472,7 +472,9 @@ bool presplit_wanted(const cumf_plan_t* p, int f, int mode) {
   static const double cap_mb = getenv("CUMF_ALS_PRESPLIT_MB") ? atof(getenv("CUMF_ALS_PRESPLIT_MB")) : 64.0;
   const int pm = presplit_mode();
   if (pm == CUMF_PRESPLIT_OFF) return false;
-  if (gram_mode() != kGramAuto || !wave_path_available(f, mode) || !presplit_supported(f) || p->gather_rows <= 0) return false;
+  if (gram_mode() != kGramAuto || !(wave_path_available(f, mode) || wave_batched_path(f, mode)) || !presplit_supported(f) ||
+      p->gather_rows <= 0)
+    return false;
   if (pm == CUMF_PRESPLIT_ON || pm == CUMF_PRESPLIT_VERIFY) return true;
   return presplit_pays(f) && (double)p->gather_rows * presplit_pitch(f) <= cap_mb * 1048576.0;
 }

@@ -556,7 +556,6 @@ __device__ __forceinline__ void stage_step(const WaveGather<NB>& wg, Planes<NB, 
 //                once per item the column groups are folded back (wave_fold_strip).  Error class of kArithSplit3 (the three
 //                dropped products ml, lm, ll are now included), not its bits in the last block column.
 // ----------------------------------------------------------------------------------
-__host__ __device__ constexpr bool presplit_shape_ok(int f) { return (f & 15) == 0 || (f & 15) == 4; }
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4* lds_tr_ptr;
 typedef char __attribute__((address_space(3)))* lds_byte_ptr;
@@ -1777,6 +1776,150 @@ __global__ __launch_bounds__(64, CUMF_WAVE_MIN_WAVES) void als_wave_kernel(const
 // als_reduce_kernel finishes the rows (LU, CG for f <= 128, or the materialised f x f Gram for
 // cg_global_kernel) -- the reference's own data flow (als.cu:782-831).
 // ----------------------------------------------------------------------------------
+// ----------------------------------------------------------------------------------
+// kArithPre for the two-wave kernel (round 6): the stage image of the pre-split table is SHARED by the two waves of the item.
+// Same construction as PreGather, sized for FB = 7 .. 12 full blocks: a rating's plane (32 FB bytes) sits in a slot of RP =
+// 320 (FB <= 9) or 448 bytes, chunk (E, p) = plane p of the four ratings 4 E + q as before; wave W fetches the ratings
+// q = 2 W, 2 W + 1 of every chunk (one global_load_lds_dwordx4 per (E, p) and wave: 24 per stage and wave instead of 52 dword
+// gathers), the strip of the ratings 16 W .. 16 W + 15 (64 bytes per rating: h | m | l of up to eight features + 16 zero
+// bytes) and their rating values.  ONE stage buffer, two barriers per stage: chunks landed + rating pieces written ->
+// barrier -> both waves read ALL blocks (6 NB transposing reads, no split: the 468 VALU instructions per stage and wave of
+// the in-kernel form are gone) -> barrier -> the chunks of the next stage -> this wave's MFMAs, which cover the gather.
+// The last block is read per plane (strip pieces | the rating piece [r_p 0 0 0] | zeros): the same operands in the same K
+// slots as the in-kernel split, the same MFMA order per tile -- bit-identical accumulators.
+// ----------------------------------------------------------------------------------
+template <int NB>
+struct PreGeo2 {
+  static constexpr int FB = NB - 1;
+  static constexpr int RP = FB <= 9 ? 320 : 448;      // = 64 or 192 (mod 256): four ratings -> four 64-byte bank groups
+  static constexpr int LP = RP / 16;
+  static constexpr int CS = 4 * RP;
+  static constexpr int kMain = 24 * CS + 3 * 32;
+  static constexpr int kStrip = kMain;                // 32 ratings x 64 B
+  static constexpr int kZero = kStrip + 2048;         // 64 B
+  static constexpr int kRating = kZero + 64;          // 32 ratings x 3 planes x 16 B
+  static constexpr int kBytes = kRating + 1536;
+  static_assert(32 * FB <= RP && 2 * LP <= 64, "a rating's plane fits its slot, two ratings fit the wave");
+  __host__ __device__ static constexpr int chunk(int E, int p) { return (3 * E + p) * CS + 32 * (E >> 1); }
+};
+
+template <int NB, int W>
+struct PreGather2 {
+  using G = PreGeo2<NB>;
+  const char* lane_base;
+  const char* zero_base;
+  const char* strip_base;
+  const char* strip_zero;
+  const int* ib;
+  const float* vb;
+  lds_tr_ptr tr_main, tr_last[2];
+  unsigned pitch;
+  int len, q, lane;
+  bool dma_active, sp;
+
+  __device__ __forceinline__ void init(const KernelArgs& a, int f, long long begin, int len_, int lane_, float* smem) {
+    lane = lane_;
+    len = len_;
+    pitch = a.pre_pitch;
+    const int spn = (f & 15) >> 2;  // strip pieces per plane: 0, 1 or 2
+    sp = spn != 0;
+    const int piece = lane % G::LP;
+    q = 2 * W + (lane / G::LP < 2 ? lane / G::LP : 1);
+    dma_active = lane < 2 * G::LP && piece < 2 * G::FB;
+    lane_base = reinterpret_cast<const char*>(a.gather) + 16 * piece;
+    zero_base = reinterpret_cast<const char*>(g_wave_zeros) + 16 * piece;
+    strip_base = reinterpret_cast<const char*>(a.gather) + 96 * G::FB + 16 * (lane & 3);
+    strip_zero = reinterpret_cast<const char*>(g_wave_zeros) + 16 * (lane & 3);
+    ib = len_ > 0 ? a.colidx + begin : reinterpret_cast<const int*>(g_wave_zeros);
+    vb = (len_ > 0 && a.val != nullptr) ? a.val + begin : g_wave_zeros;
+    const int g = lane >> 4, j = (lane >> 2) & 3, aa = lane & 3;
+    lds_byte_ptr base = (lds_byte_ptr)smem;
+    tr_main = (lds_tr_ptr)(base + 6 * g * G::CS + 32 * g + G::RP * j + 8 * aa);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int rho = 8 * g + 4 * u + j;
+      const int off = aa < spn ? G::kStrip + 64 * rho + 8 * aa : (aa == spn ? G::kRating + 48 * rho : G::kZero);
+      tr_last[u] = (lds_tr_ptr)(base + off);
+    }
+    // the zero halfwords of this wave's rating pieces (16 ratings x 48 B) and, wave 0, the zero pieces -- once; each wave only
+    // clears what it alone writes afterwards, the barrier of the first stage publishes it
+    if (lane < 48) reinterpret_cast<f32x4*>(reinterpret_cast<char*>(smem) + G::kRating + 768 * W)[lane] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (W == 0 && lane < 4) reinterpret_cast<f32x4*>(reinterpret_cast<char*>(smem) + G::kZero)[lane] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  __device__ __forceinline__ void load_idx(PreStage<NB>& st, int s) const {
+    const int top = len > 0 ? len - 1 : 0;
+#pragma unroll
+    for (int E = 0; E < 8; ++E) {
+      const int pos = kWaveStage * s + 4 * E + q;
+      st.idx[E] = ib[pos < top ? pos : top];
+    }
+    const int ps = kWaveStage * s + 16 * W + (lane >> 2);
+    st.sidx = ib[ps < top ? ps : top];
+  }
+  __device__ __forceinline__ void load_rv(PreStage<NB>& st, int s) const {
+    const int top = len > 0 ? len - 1 : 0;
+    const int pv = kWaveStage * s + 16 * W + (lane & 15);
+    const float v = vb[pv < top ? pv : top];
+    st.rv = pv < len ? v : 0.f;
+  }
+  __device__ __forceinline__ void put_rating(const PreStage<NB>& st, float* smem) const {
+    unsigned H, M, L;
+    split3_pair(st.rv, 0.f, H, M, L);
+    if (lane < 16) {
+      unsigned short* rp = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(smem) + G::kRating + 48 * (16 * W + lane));
+      rp[0] = (unsigned short)H;
+      rp[8] = (unsigned short)M;
+      rp[16] = (unsigned short)L;
+    }
+  }
+  __device__ __forceinline__ void dma_issue(const PreStage<NB>& st, float* smem, int s) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using gptr = const __attribute__((address_space(1))) void*;
+    using lptr = __attribute__((address_space(3))) void*;
+    lds_byte_ptr lds = (lds_byte_ptr)smem;
+    if (dma_active) {
+      static_for<8>([&](auto ec) {
+        constexpr int E = decltype(ec)::value;
+        const char* row = lane_base + (unsigned long long)(unsigned)st.idx[E] * pitch;
+        row = (kWaveStage * s + 4 * E + q < len) ? row : zero_base;
+        static_for<3>([&](auto pc) {
+          constexpr int p = decltype(pc)::value;
+          __builtin_amdgcn_global_load_lds((gptr)row, (lptr)(lds + G::chunk(E, p) + 2 * W * G::RP - 32 * G::FB * p), 16, 32 * G::FB * p, 0);
+        });
+      });
+    }
+    if (sp) {  // wave-uniform: the strip of the ratings 16 W .. 16 W + 15
+      const char* row = strip_base + (unsigned long long)(unsigned)st.sidx * pitch;
+      row = (kWaveStage * s + 16 * W + (lane >> 2) < len) ? row : strip_zero;
+      __builtin_amdgcn_global_load_lds((gptr)row, (lptr)(lds + G::kStrip + 1024 * W), 16, 0, 0);
+    }
+#endif
+  }
+  static __device__ __forceinline__ u32x2 tr_read(lds_tr_ptr p, int byte_off) {
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)((lds_byte_ptr)p + byte_off)));
+  }
+  __device__ __forceinline__ void read(Planes<NB>& P) const {
+    static_for<G::FB>([&](auto bc) {
+      constexpr int B = decltype(bc)::value;
+      static_for<2>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        const u32x2 vh = tr_read(tr_main, (3 * u + 0) * G::CS + 32 * B);
+        const u32x2 vm = tr_read(tr_main, (3 * u + 1) * G::CS + 32 * B);
+        const u32x2 vl = tr_read(tr_main, (3 * u + 2) * G::CS + 32 * B);
+        P.h[B][2 * u] = vh[0], P.h[B][2 * u + 1] = vh[1];
+        P.m[B][2 * u] = vm[0], P.m[B][2 * u + 1] = vm[1];
+        P.l[B][2 * u] = vl[0], P.l[B][2 * u + 1] = vl[1];
+      });
+    });
+    constexpr int B = G::FB;
+    const u32x2 h0 = tr_read(tr_last[0], 0), m0 = tr_read(tr_last[0], 16), l0 = tr_read(tr_last[0], 32);
+    const u32x2 h1 = tr_read(tr_last[1], 0), m1 = tr_read(tr_last[1], 16), l1 = tr_read(tr_last[1], 32);
+    P.h[B] = u32x4{h0[0], h0[1], h1[0], h1[1]};
+    P.m[B] = u32x4{m0[0], m0[1], m1[0], m1[1]};
+    P.l[B] = u32x4{l0[0], l0[1], l1[0], l1[1]};
+  }
+};
+
 template <int NB, int NW, int W, int MODE, int ARITH>
 __device__ __forceinline__ void multi_body(float* smem, const KernelArgs& a, long long begin, int len, int slot,
                                            int row, int rowlen, int lane) {
@@ -1787,7 +1930,47 @@ __device__ __forceinline__ void multi_body(float* smem, const KernelArgs& a, lon
 #pragma unroll
   for (int s = 0; s < TPW; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int nst = len > 0 ? (len + kWaveStage - 1) / kWaveStage : 1;  // a row without ratings: one stage on zeros
-  {
+  if constexpr (ARITH == kArithPre) {
+    PreGather2<NB, W> wg;
+    wg.init(a, f, begin, len, lane, smem);
+    PreStage<NB> R;
+    Planes<NB> P;
+    auto clamp = [&](int s) { return s < nst ? s : nst - 1; };
+    wg.load_idx(R, 0);
+    wg.dma_issue(R, smem, 0);
+    wg.load_rv(R, 0);
+    wg.load_idx(R, clamp(1));
+    for (int s = 0; s < nst; ++s) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's chunks of stage s, its indices of s + 1, its rating values of s
+      wg.put_rating(R, smem);
+      __syncthreads();                      // ... and the partner's; the rating pieces of both
+      wg.read(P);
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __syncthreads();                      // both waves have their operands: the image is free
+      if (s + 1 < nst) {                    // uniform
+        wg.dma_issue(R, smem, s + 1);
+        wg.load_idx(R, clamp(s + 2));
+        wg.load_rv(R, s + 1);
+      }
+      static_for<6>([&](auto pc) {
+        constexpr int PROD = decltype(pc)::value;
+        static_for<TPW>([&](auto sc) {
+          constexpr int t = W + NW * decltype(sc)::value;
+          if constexpr (t < NT) {
+            constexpr int I = tile_I<NB>(t), J = tile_J<NB>(t), sl = decltype(sc)::value;
+            if constexpr (PROD == 0) acc[sl] = mfma_bf16(P.l[I], P.h[J], acc[sl]);
+            if constexpr (PROD == 1) acc[sl] = mfma_bf16(P.h[I], P.l[J], acc[sl]);
+            if constexpr (PROD == 2) acc[sl] = mfma_bf16(P.m[I], P.m[J], acc[sl]);
+            if constexpr (PROD == 3) acc[sl] = mfma_bf16(P.m[I], P.h[J], acc[sl]);
+            if constexpr (PROD == 4) acc[sl] = mfma_bf16(P.h[I], P.m[J], acc[sl]);
+            if constexpr (PROD == 5) acc[sl] = mfma_bf16(P.h[I], P.h[J], acc[sl]);
+          }
+        });
+      });
+    }
+    __syncthreads();  // (the solvers alias the image: nobody may still be reading the last stage's pieces -- they are not, but the
+                      // CG's exchange buffer and the LU's are written right away)
+  } else {
     WaveGather<NB> wg;
     wg.init(a, f, begin, len, lane);
     WaveStage<NB> R;
@@ -2026,7 +2209,15 @@ hipError_t wave_item_launch<CUMF_WAVE_NB>(const KernelArgs& a, int mode, long n_
     note_item_kernel(reinterpret_cast<const void*>(kernel));
     hipLaunchKernelGGL(kernel, dim3((unsigned)n_items), dim3(128), lds, stream, a);
   };
-  if (a.fast_words) {
+  if (a.pre_words) {  // the pre-split table (round 6): one shared stage image instead of two buffers of dword chunks
+    if (mode == kModeMaterialize) return hipErrorInvalidValue;
+    lds = PreGeo2<CUMF_WAVE_NB>::kBytes;
+    if (lu_wg_lds_floats<CUMF_WAVE_NB>(a.f) * sizeof(float) > lds) lds = lu_wg_lds_floats<CUMF_WAVE_NB>(a.f) * sizeof(float);
+    if (mode == kModeCG)
+      go(als_wave_multi_kernel<CUMF_WAVE_NB, 2, kModeCG, kArithPre>);
+    else
+      go(als_wave_multi_kernel<CUMF_WAVE_NB, 2, kModeLU, kArithPre>);
+  } else if (a.fast_words) {
     if (mode == kModeMaterialize) return hipErrorInvalidValue;
     if (mode == kModeCG)
       go(als_wave_multi_kernel<CUMF_WAVE_NB, 2, kModeCG, kArithFast>);
@@ -2080,8 +2271,10 @@ hipError_t wave_cg_hist<CUMF_WAVE_NB>(unsigned long long* out16) {
 // change every half-iteration -- 7 MB read + 11 MB written for the Netflix X table).  One thread per value; the split is
 // split3_pair's, the instruction sequence of the in-kernel split: the planes are the same bits.
 // ----------------------------------------------------------------------------------
+// sw: halfwords per plane in the strip (4: the one-wave kernels' [h 4][m 4][l 4][0 4]; 8: the two-wave kernels'
+// [h 8][m 8][l 8][0 8]); what the strip's features do not fill is zero.
 __global__ __launch_bounds__(256) void presplit_bf16x3_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
-                                                              long long n, int f, int fb, unsigned pitch_halfs) {
+                                                              long long n, int f, int fb, int sw, unsigned pitch_halfs) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const long long row = i / f;
@@ -2093,23 +2286,27 @@ __global__ __launch_bounds__(256) void presplit_bf16x3_kernel(const float* __res
     r[k] = (unsigned short)H;
     r[16 * fb + k] = (unsigned short)M;
     r[32 * fb + k] = (unsigned short)L;
-  } else {  // strip: [h 4][m 4][l 4][0 4]
-    const int e = k - 16 * fb;
+  } else {
+    const int e = k - 16 * fb, sf = f - 16 * fb;
     unsigned short* st = r + 48 * fb;
     st[e] = (unsigned short)H;
-    st[4 + e] = (unsigned short)M;
-    st[8 + e] = (unsigned short)L;
-    st[12 + e] = 0;
+    st[sw + e] = (unsigned short)M;
+    st[2 * sw + e] = (unsigned short)L;
+    if (e == 0) {  // the rest of the strip: zeros
+      for (int p = 0; p < 3; ++p)
+        for (int z = sf; z < sw; ++z) st[p * sw + z] = 0;
+      for (int z = 0; z < sw; ++z) st[3 * sw + z] = 0;
+    }
   }
 }
 hipError_t launch_presplit3(const float* src, void* dst, long long rows, int f, hipStream_t stream) {
   const long long n = rows * f;
   if (n <= 0) return hipSuccess;
-  if (!presplit_shape_ok(f)) return hipErrorInvalidValue;
+  if (!presplit_supported(f)) return hipErrorInvalidValue;
   const int fb = f / 16;
-  const unsigned pitch = 96u * fb + (((f & 15) >> 2) ? 32u : 0u);
+  const unsigned pitch = presplit_pitch(f);
   hipLaunchKernelGGL(presplit_bf16x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src,
-                     static_cast<unsigned short*>(dst), n, f, fb, pitch / 2);
+                     static_cast<unsigned short*>(dst), n, f, fb, nb_for_f(f) > kMaxWaveNB ? 8 : 4, pitch / 2);
   return hipGetLastError();
 }
 #endif

@@ -42,15 +42,17 @@ def check_planes(f: int, rows: int = 257) -> dict:
     t[3, :] = 0.0
     planes = als.presplit_table(torch.from_numpy(t).cuda()).cpu().numpy()
     fb, sf = f // 16, f % 16
+    sw = 8 if f // 16 + 1 > 7 else 4   # halfwords per plane in the strip: the two-wave kernels' rows hold up to eight features
     halfs = planes.view(np.uint16).reshape(rows, -1)
     h, m, l = split_planes(t)
     ok = True
     for p, ref in enumerate((h, m, l)):
         ok &= bool(np.array_equal(halfs[:, 16 * fb * p: 16 * fb * (p + 1)], ref[:, :16 * fb]))
         if sf:
-            ok &= bool(np.array_equal(halfs[:, 48 * fb + 4 * p: 48 * fb + 4 * p + sf], ref[:, 16 * fb:]))
+            ok &= bool(np.array_equal(halfs[:, 48 * fb + sw * p: 48 * fb + sw * p + sf], ref[:, 16 * fb:]))
+            ok &= bool((halfs[:, 48 * fb + sw * p + sf: 48 * fb + sw * (p + 1)] == 0).all())
     if sf:
-        ok &= bool((halfs[:, 48 * fb + 12: 48 * fb + 16] == 0).all())
+        ok &= bool((halfs[:, 48 * fb + 3 * sw: 48 * fb + 4 * sw] == 0).all())
     # the three terms add up to the value exactly
     s = (bf16_val(h).astype(np.float64) + bf16_val(m).astype(np.float64) + bf16_val(l).astype(np.float64))
     return {"case": "planes", "f": f, "rows": rows, "pitch": int(planes.shape[1]), "planes_equal_numpy_split": ok,
@@ -153,7 +155,7 @@ def main() -> int:
             for s in a.solver:
                 print(json.dumps(time_netflix(f, s, a.reps)), flush=True)
         return 0
-    for f in a.f or [100, 64, 96, 68]:
+    for f in a.f or [100, 64, 96, 68, 200, 128, 120, 180]:
         o = check_planes(f)
         bad += not (o["planes_equal_numpy_split"] and o["h_plus_m_plus_l_exact"])
         print(json.dumps(o), flush=True)
