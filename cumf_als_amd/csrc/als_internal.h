@@ -153,6 +153,10 @@ __host__ __device__ constexpr bool presplit_supported(int f) {
 // SIMD that the 160-register kernel otherwise gets (10 KB of dword chunks): measured SLOWER, Netflix f = 64 LU Theta side
 // 5.6-5.9 -> 6.4-6.5 ms (profiles/r06/ab_presplit_f64_lu.txt); the kernels stay for CUMF_PRESPLIT_ON and the tests.
 __host__ __device__ constexpr bool presplit_pays(int f) { return presplit_supported(f) && nb_for_f(f) >= 7; }
+// ... and regardless of the table's size from NB = 10 on (f >= 144): there the two-wave kernel is bound by its matrix-pipe and
+// split work, not by the gather -- Netflix f = 200, X side (a 384 MB table, 584 MB of planes): 28.8 -> 26.3 ms (CG), 29.5 ->
+// 26.8 (LU); at f = 128 (NB = 9) the X side gains nothing (profiles/r06/ab_presplit_multi.txt)
+__host__ __device__ constexpr bool presplit_pays_any_size(int f) { return presplit_supported(f) && nb_for_f(f) >= 10; }
 __host__ __device__ constexpr unsigned presplit_pitch(int f) {
   return 96u * (f / 16) + ((f & 15) ? (nb_for_f(f) > kMaxWaveNB ? 64u : 32u) : 0u);
 }

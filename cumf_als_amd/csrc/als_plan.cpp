@@ -476,7 +476,7 @@ bool presplit_wanted(const cumf_plan_t* p, int f, int mode) {
       p->gather_rows <= 0)
     return false;
   if (pm == CUMF_PRESPLIT_ON || pm == CUMF_PRESPLIT_VERIFY) return true;
-  return presplit_pays(f) && (double)p->gather_rows * presplit_pitch(f) <= cap_mb * 1048576.0;
+  return presplit_pays_any_size(f) || (presplit_pays(f) && (double)p->gather_rows * presplit_pitch(f) <= cap_mb * 1048576.0);
 }
 int pre_words(const cumf_plan_t* p, const float* gather, int f, hipStream_t stream, KernelArgs* a) {
   void* planes = nullptr;

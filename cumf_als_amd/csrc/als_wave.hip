@@ -1898,9 +1898,10 @@ struct PreGather2 {
   static __device__ __forceinline__ u32x2 tr_read(lds_tr_ptr p, int byte_off) {
     return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)((lds_byte_ptr)p + byte_off)));
   }
-  __device__ __forceinline__ void read(Planes<NB>& P) const {
-    static_for<G::FB>([&](auto bc) {
-      constexpr int B = decltype(bc)::value;
+  template <int B0, int B1>
+  __device__ __forceinline__ void read_blocks(Planes<NB>& P) const {
+    static_for<B1 - B0>([&](auto bc) {
+      constexpr int B = B0 + decltype(bc)::value;
       static_for<2>([&](auto uc) {
         constexpr int u = decltype(uc)::value;
         const u32x2 vh = tr_read(tr_main, (3 * u + 0) * G::CS + 32 * B);
@@ -1911,6 +1912,8 @@ struct PreGather2 {
         P.l[B][2 * u] = vl[0], P.l[B][2 * u + 1] = vl[1];
       });
     });
+  }
+  __device__ __forceinline__ void read_last(Planes<NB>& P) const {
     constexpr int B = G::FB;
     const u32x2 h0 = tr_read(tr_last[0], 0), m0 = tr_read(tr_last[0], 16), l0 = tr_read(tr_last[0], 32);
     const u32x2 h1 = tr_read(tr_last[1], 0), m1 = tr_read(tr_last[1], 16), l1 = tr_read(tr_last[1], 32);
@@ -1941,10 +1944,42 @@ __device__ __forceinline__ void multi_body(float* smem, const KernelArgs& a, lon
     wg.load_rv(R, 0);
     wg.load_idx(R, clamp(1));
     for (int s = 0; s < nst; ++s) {
+      // this wave's MFMAs in two groups (as the one-wave stage_step_pk): the tiles among the first HB blocks run under the
+      // transposing reads of the other blocks; the order of the six products of any one tile is unchanged
+      constexpr int HB = NB / 2;
+      auto group = [&](auto first) {
+        constexpr bool FIRST = decltype(first)::value;
+        static_for<6>([&](auto pc) {
+          constexpr int PROD = decltype(pc)::value;
+          static_for<TPW>([&](auto sc) {
+            constexpr int t = W + NW * decltype(sc)::value;
+            if constexpr (t < NT) {
+              constexpr int I = tile_I<NB>(t), J = tile_J<NB>(t), sl = decltype(sc)::value;
+              if constexpr ((J < HB) == FIRST) {
+                if constexpr (PROD == 0) acc[sl] = mfma_bf16(P.l[I], P.h[J], acc[sl]);
+                if constexpr (PROD == 1) acc[sl] = mfma_bf16(P.h[I], P.l[J], acc[sl]);
+                if constexpr (PROD == 2) acc[sl] = mfma_bf16(P.m[I], P.m[J], acc[sl]);
+                if constexpr (PROD == 3) acc[sl] = mfma_bf16(P.m[I], P.h[J], acc[sl]);
+                if constexpr (PROD == 4) acc[sl] = mfma_bf16(P.h[I], P.m[J], acc[sl]);
+                if constexpr (PROD == 5) acc[sl] = mfma_bf16(P.h[I], P.h[J], acc[sl]);
+              }
+            }
+          });
+        });
+      };
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's chunks of stage s, its indices of s + 1, its rating values of s
       wg.put_rating(R, smem);
       __syncthreads();                      // ... and the partner's; the rating pieces of both
-      wg.read(P);
+      wg.template read_blocks<0, HB>(P);
+      __builtin_amdgcn_sched_barrier(0);
+      wg.template read_blocks<HB, NB - 1>(P);
+      wg.read_last(P);
+      group(std::true_type{});
+      static_for<6 * (NB - HB)>([&](auto) {  // the late reads one behind each of the first MFMAs (<= 16 LDS operations in flight)
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      });
+      __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_waitcnt(0xC07F);
       __syncthreads();                      // both waves have their operands: the image is free
       if (s + 1 < nst) {                    // uniform
@@ -1952,21 +1987,7 @@ __device__ __forceinline__ void multi_body(float* smem, const KernelArgs& a, lon
         wg.load_idx(R, clamp(s + 2));
         wg.load_rv(R, s + 1);
       }
-      static_for<6>([&](auto pc) {
-        constexpr int PROD = decltype(pc)::value;
-        static_for<TPW>([&](auto sc) {
-          constexpr int t = W + NW * decltype(sc)::value;
-          if constexpr (t < NT) {
-            constexpr int I = tile_I<NB>(t), J = tile_J<NB>(t), sl = decltype(sc)::value;
-            if constexpr (PROD == 0) acc[sl] = mfma_bf16(P.l[I], P.h[J], acc[sl]);
-            if constexpr (PROD == 1) acc[sl] = mfma_bf16(P.h[I], P.l[J], acc[sl]);
-            if constexpr (PROD == 2) acc[sl] = mfma_bf16(P.m[I], P.m[J], acc[sl]);
-            if constexpr (PROD == 3) acc[sl] = mfma_bf16(P.m[I], P.h[J], acc[sl]);
-            if constexpr (PROD == 4) acc[sl] = mfma_bf16(P.h[I], P.m[J], acc[sl]);
-            if constexpr (PROD == 5) acc[sl] = mfma_bf16(P.h[I], P.h[J], acc[sl]);
-          }
-        });
-      });
+      group(std::false_type{});
     }
     __syncthreads();  // (the solvers alias the image: nobody may still be reading the last stage's pieces -- they are not, but the
                       // CG's exchange buffer and the LU's are written right away)
