@@ -1,7 +1,8 @@
-// als_lu_blocked.h -- the pieces of the blocked elimination (round 4: lu_wave_blocked, als_wave.hip) that the wave kernels
-// share with the row-owning workgroup LU of the large systems (round 5: als_lu_rows.h): the exact bf16x3 split, the
-// preparation of one four-pivot panel on the accumulators of ONE wave (DPP quad broadcasts + ds_bpermute, no barrier),
-// the rank-16 bf16 MFMA.
+// als_lu_blocked.h -- the pieces of the blocked elimination (round 4: lu_wave_blocked, als_wave.hip): the exact bf16x3 split
+// (also the Gram stage's and the pre-split kernel's), the preparation of one four-pivot panel on the accumulators of ONE wave
+// (DPP quad broadcasts + ds_bpermute, no barrier), the rank-16 bf16 MFMA.  (Round 5 shared them with a row-owning workgroup
+// LU of the large systems that was built, was correct and was slower: it lives as profiles/r05/lu_rows_experiment.patch,
+// not in the tree.)
 #pragma once
 #include "als_device.h"
 
@@ -109,16 +110,11 @@ __device__ __forceinline__ float fma_quad_bcast(float t, float n, float acc) {
 // registers 0..3 of the diagonal tile -- by every lane on its own column with DPP quad broadcasts: N_ij += (N_0i / u_00) N_0j
 // etc.  No v_readlane (10 + 7 v_mov per panel), no wave-uniform scalar chain; the rows of E and 1 / sqrt(u_kk) come out in
 // quad lane kk and reach lane group kk with four ds_bpermute.  ~30 VALU per panel instead of ~66.
-// MAP::slot(t): where the wave keeps tile t (the wave kernels: the tile number itself; the row-owning waves of
-// als_lu_rows.h: its position among the wave's own tiles).
-struct LuIdentityMap {
-  static constexpr int slot(int t) { return t; }
-};
-template <int NB, int Ip, int q, bool DYN, int STEP, class MAP = LuIdentityMap, class ACC>
+template <int NB, int Ip, int q, bool DYN, int STEP, class ACC>
 __device__ __forceinline__ void lu_prep_step_s(const ACC& acc, LuPrepS<NB>& s, float (&w)[NB], float& wm,
                                                float* rdiag, int f, const LuLaneS& ln, int dbg = 0) {
   constexpr int L = NB - Ip;
-  constexpr int SD = MAP::slot(tile_of<NB>(Ip, Ip));
+  constexpr int SD = tile_of<NB>(Ip, Ip);
   constexpr int p0 = 16 * Ip + 4 * q;
   auto sel = [](bool p, float a, float b) { return p ? a : b; };
   auto rsq = [](float d) { return __builtin_amdgcn_rsqf(d); };
@@ -135,7 +131,7 @@ __device__ __forceinline__ void lu_prep_step_s(const ACC& acc, LuPrepS<NB>& s, f
     s.n3 = fma_quad_bcast<3>(s.t0, s.n0, s.n3);
   } else if constexpr (STEP <= L) {
     constexpr int b = Ip + STEP - 1;
-    constexpr int t = MAP::slot(tile_of<NB>(Ip, b));
+    constexpr int t = tile_of<NB>(Ip, b);
     const int src = 4 * (16 * q + ln.c);  // byte address of lane (q, c)
     // (the element goes through a float first: __builtin_bit_cast applied to a vector-element lvalue reads element 0)
 #if CUMF_ABLATE
@@ -195,7 +191,7 @@ __device__ __forceinline__ void lu_prep_step_s(const ACC& acc, LuPrepS<NB>& s, f
     // profiling build: 8192 = the eliminated rows of the blocks right of the diagonal tile by ONE fp32 MFMA on the
     // accumulator registers (what a stride-4 pivot order would issue; wrong values here)
     if ((dbg & 8192) && b > Ip) {
-      const f32x4 z = __builtin_amdgcn_mfma_f32_16x16x4f32(s.e0 * s.rsk, acc[MAP::slot(tile_of<NB>(Ip, b))][q], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      const f32x4 z = __builtin_amdgcn_mfma_f32_16x16x4f32(s.e0 * s.rsk, acc[tile_of<NB>(Ip, b)][q], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
       w[b] = z[0];
       return;
     }

@@ -195,7 +195,7 @@ __device__ __forceinline__ void lu_solve_mfma(LuAcc<NB, NW>& acc, float* __restr
                                               int rowlen = 0) {
   constexpr int NT = LuGeo<NB, NW>::NT, TPW = LuGeo<NB, NW>::TPW;
   const int lane = tid & 63, c = lane & 15, kk = lane >> 4;
-  float* X = lds;                                 // published raw panel rows, [parity][r][16 NB]
+  float* X = lds;                                 // published raw panel rows, [parity][column 16 J + c][r]: the four rows of a column side by side (one 16-byte access)
   float* Twin = lds + LuLds<NB>::kX;              // back-substitution window
   float* rdiag = Twin + LuLds<NB>::kT;            // pivot reciprocals
   // lambda * n_u on the diagonal (als.cu:545-557)

@@ -375,7 +375,10 @@ __device__ __forceinline__ void gram_mfma(const Planes<NB>& P, f32x4 (&acc)[NB *
 // a 16 x 16 transpose through the idle stage buffer).  2 NB of the 6 NT MFMAs of every stage go: 14 of 168 at f = 100.
 // The doubled plane lives for three MFMAs: [2h l^T on (I, I)] [an independent tile] [2h m^T on (I, I)].
 // Exponent + 1 on a bf16 zero gives 2^-126 -- multiplied by the m / l of a zero value, which are zero; an Inf / NaN still
-// reaches the accumulator through hh.
+// reaches the accumulator through hh.  Supported range: finite values with |x| < 2^127 whose leading term h is a
+// NORMAL bf16 number or zero -- at biased exponent 0xFE the increment wraps into the Inf / NaN encodings, and a subnormal h is
+// not doubled by it; there the diagonal tile's D + 2 S differs from the six-product form of the off-diagonal tiles (factors
+// of that size do not occur in ALS: test_split_gram_adversarial_per_entry covers 1e-36 products and nine decades).
 // ----------------------------------------------------------------------------------
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u32x4 bf16x8_times2(u32x4 v) {
@@ -419,9 +422,11 @@ __host__ __device__ constexpr GramSched<NB> make_gram_sched() {
   for (int t = 0; t < NT; ++t) { s.tile[n] = t; s.kind[n++] = kHH; }
   return s;
 }
-// h2: the doubled plane, two copies used in turn by successive feature blocks -- the block that is doubled next never
-// writes the registers the MFMA just issued still reads (the 128-bit operands of this MFMA are read over more than one
-// cycle: als_lu_rows.h, mfma_bf16_k32).
+// h2: the doubled plane, two copies used in turn by successive feature blocks (a write straight behind the MFMA that reads a
+// register measured safe; what the hardware does need is wait states between the v_pk_add_u16 that WRITES h2 and the MFMA
+// that reads it -- two for dword 0 / 1 of the operand quad, one for dword 2 / 3: tools/probes/mfma_k32_hazard_probe.hip,
+// profiles/r05/mfma_k32_operand_hazard.txt.  The compiler's hazard recogniser supplies them (s_nop); that it does is checked
+// on the shipped ISA by tests/test_capi_symbols.py::test_k32_mfma_operand_wait_states_in_wave_kernels.)
 template <int NB, int N>
 __device__ __forceinline__ void gram_mfma_sched(const Planes<NB>& P, f32x4 (&acc)[NB * (NB + 1) / 2], u32x4 (&h2)[2]) {
   constexpr GramSched<NB> S = make_gram_sched<NB>();
