@@ -432,9 +432,6 @@ __device__ __forceinline__ void gram_mfma_sched(const Planes<NB>& P, f32x4 (&acc
   constexpr GramSched<NB> S = make_gram_sched<NB>();
   constexpr int t = S.tile[N], kind = S.kind[N];
   constexpr int I = tile_I<NB>(t), J = tile_J<NB>(t);
-#ifdef CUMF_EXP_STRIP  // timing experiment only (wrong results): the last tile column at 3 products / 1 on its diagonal tile
-  if constexpr (J == NB - 1 && (kind == kLH || kind == kHL || kind == kMH || kind == kD2L || kind == kD2M || (I == J && kind == kMM))) return;
-#endif
   if constexpr (kind == kLH) acc[t] = mfma_bf16(P.l[I], P.h[J], acc[t]);
   if constexpr (kind == kHL) acc[t] = mfma_bf16(P.h[I], P.l[J], acc[t]);
   if constexpr (kind == kMM) acc[t] = mfma_bf16(P.m[I], P.m[J], acc[t]);
