@@ -1187,6 +1187,23 @@ __device__ __forceinline__ void lu_trailing_mfma(f32x4 (&acc)[NB * (NB + 1) / 2]
   if constexpr (PROD == 5) acc[t] = mfma_bf16_k16(h[I], h[J], acc[t]);
 }
 
+// product PROD of the rank-32 update of tile t by TWO block rows at once (round 6): K slots 0 .. 3 of a lane = the first row's
+// four pivots 4 e + g, slots 4 .. 7 = the second row's -- v_mfma_f32_16x16x16_bf16 costs what the K = 32 form costs, so pairing
+// the block rows halves the MFMAs of every tile that lies below both (204 instead of 336 per 100 x 100 system)
+template <int NB, int t, int PROD>
+__device__ __forceinline__ void lu_trailing_mfma32(f32x4 (&acc)[NB * (NB + 1) / 2], const u32x2 (&hA)[NB], const u32x2 (&mA)[NB],
+                                                   const u32x2 (&lA)[NB], const u32x2 (&hB)[NB], const u32x2 (&mB)[NB],
+                                                   const u32x2 (&lB)[NB]) {
+  constexpr int I = tile_I<NB>(t), J = tile_J<NB>(t);
+  auto q = [](const u32x2& a, const u32x2& b) { return u32x4{a[0], a[1], b[0], b[1]}; };
+  if constexpr (PROD == 0) acc[t] = mfma_bf16(q(lA[I], lB[I]), q(hA[J], hB[J]), acc[t]);
+  if constexpr (PROD == 1) acc[t] = mfma_bf16(q(hA[I], hB[I]), q(lA[J], lB[J]), acc[t]);
+  if constexpr (PROD == 2) acc[t] = mfma_bf16(q(mA[I], mB[I]), q(mA[J], mB[J]), acc[t]);
+  if constexpr (PROD == 3) acc[t] = mfma_bf16(q(mA[I], mB[I]), q(hA[J], hB[J]), acc[t]);
+  if constexpr (PROD == 4) acc[t] = mfma_bf16(q(hA[I], hB[I]), q(mA[J], mB[J]), acc[t]);
+  if constexpr (PROD == 5) acc[t] = mfma_bf16(q(hA[I], hB[I]), q(hA[J], hB[J]), acc[t]);
+}
+
 template <int NB, int FC>
 __device__ __forceinline__ float lu_wave_blocked(f32x4 (&acc)[NB * (NB + 1) / 2], float* T, int f_rt, float reg,
                                                  float* __restrict__ x_global, int lane, int dbg = 0) {
@@ -1220,14 +1237,19 @@ __device__ __forceinline__ float lu_wave_blocked(f32x4 (&acc)[NB * (NB + 1) / 2]
   // ONE MFMA AT A TIME IN FRONT OF THE MICRO-STEPS of the next block row's panels: a bf16 MFMA runs beside the VALU work
   // of its own wave only when the two alternate in program order (in-order issue), and the partner wave covers but a
   // third of a burst (measured: the update in one burst per block row costs 0.92 ms of the Theta side's 4.6 ms solve).
-  u32x2 h[NB], m[NB], l[NB];
+  // Round 6: block rows in PAIRS.  The first row of a pair (Ip even) updates only the second row's tiles at once (rank 16: its
+  // panels read them); everything below both waits for the second row and then takes ONE rank-32 update with the planes of
+  // both (A, B) -- the tiles of the next block row at once, the rest one MFMA at a time in front of the micro-steps of the NEXT
+  // pair's first row.
+  u32x2 hA[NB], mA[NB], lA[NB], hB[NB], mB[NB], lB[NB];
 #pragma unroll
-  for (int b = 0; b < NB; ++b) h[b] = m[b] = l[b] = u32x2{0u, 0u};
+  for (int b = 0; b < NB; ++b) hA[b] = mA[b] = lA[b] = hB[b] = mB[b] = lB[b] = u32x2{0u, 0u};
   static_for<NB>([&](auto ipc) {
     constexpr int Ip = decltype(ipc)::value;
     constexpr int L = NB - Ip;
-    // pending: block row Ip - 1's update of the tiles below block row Ip
-    constexpr int NTl = Ip >= 1 ? (L - 1) * L / 2 : 0;  // tiles of rows Ip + 1 .. NB - 1
+    constexpr bool FIRST = (Ip & 1) == 0;
+    // pending (first rows only): the previous pair's rank-32 update of the tiles below block row Ip
+    constexpr int NTl = (FIRST && Ip >= 2) ? (L - 1) * L / 2 : 0;  // tiles of rows Ip + 1 .. NB - 1
     constexpr int TP = 6 * NTl;
     constexpr int S = lu_prep_steps<NB, Ip>();
     float w[4][NB];  // w[e][b]: panel e of this block row at feature block b >= Ip
@@ -1254,7 +1276,7 @@ __device__ __forceinline__ float lu_wave_blocked(f32x4 (&acc)[NB * (NB + 1) / 2]
           constexpr int n0 = gs * TP / (4 * S), n1 = (gs + 1) * TP / (4 * S);
           static_for<n1 - n0>([&](auto nc) {
             constexpr int n = n0 + decltype(nc)::value;
-            lu_trailing_mfma<NB, lu_trailing_tile<NB, Ip + 1>(n % NTl), n / NTl>(acc, h, m, l);
+            lu_trailing_mfma32<NB, lu_trailing_tile<NB, Ip + 1>(n % NTl), n / NTl>(acc, hA, mA, lA, hB, mB, lB);
           });
 #if CUMF_ABLATE
           lu_prep_step_s<NB, Ip, q, dynp, i>(acc, s, w[q], wm, rdiag, f, ln, dbg);
@@ -1284,17 +1306,25 @@ __device__ __forceinline__ float lu_wave_blocked(f32x4 (&acc)[NB * (NB + 1) / 2]
     if (!(dbg & 1024))  // profiling build: 1024 = no trailing update
 #endif
     if constexpr (L > 1) {
-      // planes of this block row's w; the tiles of block row Ip + 1 at once, block by block as the planes appear
+      // planes of this block row's w; the tiles of block row Ip + 1 at once, block by block as the planes appear: rank 16 by
+      // the first row of a pair, rank 32 (both rows' planes) by the second
       static_for<L - 1>([&](auto bc2) {
         constexpr int b = Ip + 1 + decltype(bc2)::value;
         unsigned H0, M0, L0, H1, M1, L1;
         split3_pair(w[0][b], w[1][b], H0, M0, L0);
         split3_pair(w[2][b], w[3][b], H1, M1, L1);
-        h[b] = u32x2{H0, H1};
-        m[b] = u32x2{M0, M1};
-        l[b] = u32x2{L0, L1};
         constexpr int t = tile_of<NB>(Ip + 1, b);
-        static_for<6>([&](auto pc) { lu_trailing_mfma<NB, t, decltype(pc)::value>(acc, h, m, l); });
+        if constexpr (FIRST) {
+          hA[b] = u32x2{H0, H1};
+          mA[b] = u32x2{M0, M1};
+          lA[b] = u32x2{L0, L1};
+          static_for<6>([&](auto pc) { lu_trailing_mfma<NB, t, decltype(pc)::value>(acc, hA, mA, lA); });
+        } else {
+          hB[b] = u32x2{H0, H1};
+          mB[b] = u32x2{M0, M1};
+          lB[b] = u32x2{L0, L1};
+          static_for<6>([&](auto pc) { lu_trailing_mfma32<NB, t, decltype(pc)::value>(acc, hA, mA, lA, hB, mB, lB); });
+        }
       });
       __builtin_amdgcn_sched_barrier(0);
     }
