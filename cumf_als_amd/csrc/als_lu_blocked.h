@@ -112,7 +112,7 @@ __device__ __forceinline__ float fma_quad_bcast(float t, float n, float acc) {
 // quad lane kk and reach lane group kk with four ds_bpermute.  ~30 VALU per panel instead of ~66.
 template <int NB, int Ip, int q, bool DYN, int STEP, class ACC>
 __device__ __forceinline__ void lu_prep_step_s(const ACC& acc, LuPrepS<NB>& s, float (&w)[NB], float& wm,
-                                               float* rdiag, int f, const LuLaneS& ln, int dbg = 0) {
+                                               float* rdiag, float* xbuf, int f, const LuLaneS& ln, int dbg = 0) {
   constexpr int L = NB - Ip;
   constexpr int SD = tile_of<NB>(Ip, Ip);
   constexpr int p0 = 16 * Ip + 4 * q;
@@ -123,6 +123,15 @@ __device__ __forceinline__ void lu_prep_step_s(const ACC& acc, LuPrepS<NB>& s, f
   };
   const bool v1 = !DYN || p0 + 1 < f, v2 = !DYN || p0 + 2 < f, v3 = !DYN || p0 + 3 < f;
   if constexpr (STEP == 0) {
+    // Round 6: the panel's raw rows reach the other lane groups through LDS -- every lane stores the four rows it holds of
+    // every live block (one 16-byte store per block: [lane group][block][column][row r]), every lane then loads the four rows
+    // of lane group q at its column (one 16-byte load per block, steps 1 .. L; the 16 lanes of a column read one address) --
+    // instead of four ds_bpermute per block: 2 L LDS instructions per panel instead of 4 L (LDS operations of one wave
+    // execute in order: no barrier).
+    static_for<L>([&](auto bc) {
+      constexpr int b = Ip + decltype(bc)::value;
+      *reinterpret_cast<f32x4*>(xbuf + ((ln.kk * NB + b) * 16 + ln.c) * 4) = acc[tile_of<NB>(Ip, b)];
+    });
     s.n0 = acc[SD][0], s.n1 = acc[SD][1], s.n2 = acc[SD][2], s.n3 = acc[SD][3];
     s.rs0 = rsq(-quad_bcast<0>(s.n0));
     s.t0 = s.n0 * (s.rs0 * s.rs0);  // quad lane i: m_i0 = N_0i / u_00
@@ -131,20 +140,17 @@ __device__ __forceinline__ void lu_prep_step_s(const ACC& acc, LuPrepS<NB>& s, f
     s.n3 = fma_quad_bcast<3>(s.t0, s.n0, s.n3);
   } else if constexpr (STEP <= L) {
     constexpr int b = Ip + STEP - 1;
-    constexpr int t = tile_of<NB>(Ip, b);
-    const int src = 4 * (16 * q + ln.c);  // byte address of lane (q, c)
-    // (the element goes through a float first: __builtin_bit_cast applied to a vector-element lvalue reads element 0)
 #if CUMF_ABLATE
-    // profiling build: 4096 / 8192 = the panel rows of the blocks right of the diagonal tile without their broadcast
+    // profiling build: 4096 / 8192 = the panel rows of the blocks right of the diagonal tile without their exchange
     if ((dbg & (4096 | 8192)) && b > Ip) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) s.R[b][r] = acc[t][r];
+      for (int r = 0; r < 4; ++r) s.R[b][r] = acc[tile_of<NB>(Ip, b)][r];
     } else
 #endif
+    {
+      const f32x4 rr = *reinterpret_cast<const f32x4*>(xbuf + ((q * NB + b) * 16 + ln.c) * 4);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float v = acc[t][r];
-      s.R[b][r] = bperm(src, v);
+      for (int r = 0; r < 4; ++r) s.R[b][r] = rr[r];
     }
   } else if constexpr (STEP == L + 1) {
     const float d = -quad_bcast<1>(s.n1);

@@ -1043,10 +1043,14 @@ __device__ __forceinline__ void wave_tiles_to_global(const f32x4 (&acc)[NB * (NB
 // (LDS operations of one wave execute in order: the window is rewritten behind the reads).
 // ----------------------------------------------------------------------------------
 constexpr int kBsPitch = 17;
+// window + pivot reciprocals + 16 zeros + dummy line, then (16-byte aligned) the panel-row exchange of lu_prep_step_s:
+// 4 lane groups x NB blocks x 16 columns x 4 rows
 template <int NB>
-__host__ __device__ constexpr int wave_lu_lds_floats(int f) {
-  return 16 * NB * kBsPitch + ((f + 3) & ~3) + 16 + 64;  // window + pivot reciprocals + 16 zeros + dummy line
+__host__ __device__ constexpr int wave_lu_xbuf_offset(int f) {
+  return (16 * NB * kBsPitch + ((f + 3) & ~3) + 16 + 64 + 3) & ~3;
 }
+template <int NB>
+__host__ __device__ constexpr int wave_lu_lds_floats(int f) { return wave_lu_xbuf_offset<NB>(f) + 4 * NB * 64; }
 template <int NB, int ARITH = kArithSplit3>
 __host__ __device__ constexpr int wave_stage_lds_floats() {
   if constexpr (ARITH == kArithPre || ARITH == kArithPrePk)
@@ -1230,6 +1234,7 @@ __device__ __forceinline__ float lu_wave_blocked(f32x4 (&acc)[NB * (NB + 1) / 2]
   float* rdiag = T + 16 * NB * kBsPitch;  // pivot reciprocals, then 16 zeros (rows outside a pivot block read these)
   float* zpad = rdiag + ((f + 3) & ~3);
   if (lane < 16) zpad[lane] = 0.f;
+  float* xbuf = T + wave_lu_xbuf_offset<NB>(f);  // panel-row exchange: [lane group 4][block NB][column 16][row 4]
 
   LuPrepS<NB> s;
   // bf16 planes of the w of the block row that has just been eliminated (blocks below it): the operands of its rank-16
@@ -1279,9 +1284,9 @@ __device__ __forceinline__ float lu_wave_blocked(f32x4 (&acc)[NB * (NB + 1) / 2]
             lu_trailing_mfma32<NB, lu_trailing_tile<NB, Ip + 1>(n % NTl), n / NTl>(acc, hA, mA, lA, hB, mB, lB);
           });
 #if CUMF_ABLATE
-          lu_prep_step_s<NB, Ip, q, dynp, i>(acc, s, w[q], wm, rdiag, f, ln, dbg);
+          lu_prep_step_s<NB, Ip, q, dynp, i>(acc, s, w[q], wm, rdiag, xbuf, f, ln, dbg);
 #else
-          lu_prep_step_s<NB, Ip, q, dynp, i>(acc, s, w[q], wm, rdiag, f, ln);
+          lu_prep_step_s<NB, Ip, q, dynp, i>(acc, s, w[q], wm, rdiag, xbuf, f, ln);
 #endif
           if constexpr (TP > 0) __builtin_amdgcn_sched_barrier(0);
         });
