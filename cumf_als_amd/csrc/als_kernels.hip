@@ -704,7 +704,7 @@ template <int NB, int MODE, int W>
 __device__ __forceinline__ void finish_row(f32x4 (&acc)[Geo<NB>::TPW], float* smem, const KernelArgs& a, int row,
                                            int rowlen, int tid) {
   if constexpr (MODE == kModeLU && lu_on_accumulators(NB)) {
-    lu_solve_mfma<NB, W>(acc, smem, a.f, (float)rowlen * a.lambda, a.update + (size_t)row * a.f, tid, a.sse_bins, rowlen);
+    lu_solve_wg<NB, W>(acc, smem, a.f, (float)rowlen * a.lambda, a.update + (size_t)row * a.f, tid, a.sse_bins, rowlen);
   } else {
     dump_row<NB, MODE, W>(acc, smem, a, row, rowlen, tid & 63);
   }
@@ -884,7 +884,10 @@ __device__ __forceinline__ void reduce_body(float* smem, const KernelArgs& a, in
 // worth more than the registers it spills at 128 (118 at NB = 13, 28 at NB = 12; NB <= 11 fit anyway) -- Netflix f = 200 LU
 // Theta side 74.5 -> 71.4 ms (profiles/r06/ab_r13w4.txt).
 template <int NB, int MODE>
-__global__ __launch_bounds__(kThreads, (NB >= 12 && MODE == kModeLU) ? 4 : 1) void als_reduce_kernel(const KernelArgs a) {
+#ifndef CUMF_REDUCE_LU_WGS
+#define CUMF_REDUCE_LU_WGS 4
+#endif
+__global__ __launch_bounds__(kThreads, (NB >= 11 && MODE == kModeLU) ? CUMF_REDUCE_LU_WGS : 1) void als_reduce_kernel(const KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int mr = blockIdx.x;
@@ -892,7 +895,11 @@ __global__ __launch_bounds__(kThreads, (NB >= 12 && MODE == kModeLU) ? 4 : 1) vo
   const int slot0 = a.dense_slots ? mr : a.mrow_slot0[mr];
   const int nslots = a.dense_slots ? 1 : a.mrow_nslots[mr];
   const int rowlen = a.mrow_rowlen[mr];
-  switch (tid >> 6) {
+  // Role of this wave, rotated with the workgroup index as in als_item_kernel: the LU loads the roles unevenly (role 0 runs
+  // the back substitution alone, the owner of a diagonal tile eliminates the pivot blocks), and the waves of a workgroup go
+  // to fixed SIMDs -- without the rotation one SIMD of every CU carries all the heavy roles.
+  const int role = (MODE == kModeLU && lu_on_accumulators(NB)) ? (((tid >> 6) + (mr >> 8) + (mr >> 10)) & 3) : (tid >> 6);
+  switch (role) {
     case 0: reduce_body<NB, MODE, 0>(smem, a, row, slot0, nslots, rowlen, lane); break;
     case 1: reduce_body<NB, MODE, 1>(smem, a, row, slot0, nslots, rowlen, lane); break;
     case 2: reduce_body<NB, MODE, 2>(smem, a, row, slot0, nslots, rowlen, lane); break;

@@ -2123,7 +2123,7 @@ __device__ __forceinline__ void multi_body(float* smem, const KernelArgs& a, lon
       cg_wave_core<NB, NW, W>(acc, smem, a, f, row, rowlen, lane);
     } else {
       __syncthreads();  // the partner is done with the stage buffers: the LU's exchange buffers alias them
-      lu_solve_mfma<NB, W, NW>(acc, smem, f, (float)rowlen * a.lambda, a.update + (size_t)row * f, lane, a.sse_bins, rowlen);
+      lu_solve_wg<NB, W, NW>(acc, smem, f, (float)rowlen * a.lambda, a.update + (size_t)row * f, lane, a.sse_bins, rowlen);
     }
     return;
   }
