@@ -99,6 +99,9 @@ struct KernelArgs {
   // fused train SSE (als.cu:979-991 folded into the Theta update): when not null, every whole-row item of a wave-kernel
   // launch adds sum_u (r_uv - x_u . theta_v)^2 of its row to sse_bins[item % kSseBins] (fp64 atomics)
   double* sse_bins;
+  // the fp32 gather table itself (`gather` is replaced by the pre-split planes / f16 words of a launch that uses them): what
+  // the Gram-free CG of short rows reads (als_short.hip)
+  const float* gather_f32;
 };
 constexpr int kSseBins = 1024;
 
@@ -115,7 +118,12 @@ struct PlanLists {
   float* part2;      // dense-slot tile buffer of the batched path (lazily allocated), part2_rows slots
   long part2_rows;
   double chunk_share;  // share of the plan's ratings that sits in chunked rows
+  long n_short;        // whole rows of at most kShortRow ratings: the LAST n_short items of the full list (and of the w list)
 };
+// Rows this short have a CG of their own that never forms the Gram matrix (als_short.hip); plans list them last.
+constexpr int kShortRow = 32;
+bool short_cg_available(int f);
+hipError_t launch_short_cg(const KernelArgs& a, long n_items, hipStream_t stream);
 hipError_t launch_half_iteration(const KernelArgs& a, int mode, long n_items, long n_mrows, hipStream_t stream,
                                  const PlanLists* lists = nullptr);
 hipError_t launch_solve_batched(const float* A, const float* b, float* x, long batch, int f, int mode, int cg_iters,

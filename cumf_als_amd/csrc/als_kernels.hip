@@ -369,7 +369,8 @@ __device__ __forceinline__ void tiles_to_partial(const f32x4 (&acc)[Geo<NB>::TPW
     }
   });
 }
-template <int NB, int W>
+// NEG: the sum of the partial tiles NEGATED (what the blocked workgroup LU eliminates: lu_solve_blocked_wg)
+template <int NB, int W, bool NEG = false>
 __device__ __forceinline__ void partial_accumulate(f32x4 (&acc)[Geo<NB>::TPW], const float* __restrict__ part,
                                                    int lane) {
   constexpr int NT = Geo<NB>::NT, TPW = Geo<NB>::TPW;
@@ -378,7 +379,10 @@ __device__ __forceinline__ void partial_accumulate(f32x4 (&acc)[Geo<NB>::TPW], c
     constexpr int t = Geo<NB>::tile(W, s);
     if constexpr (t < NT) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[s][r] += part[((size_t)t * 4 + r) * 64 + lane];
+      for (int r = 0; r < 4; ++r) {
+        const float v = part[((size_t)t * 4 + r) * 64 + lane];
+        acc[s][r] = NEG ? acc[s][r] - v : acc[s][r] + v;
+      }
     }
   });
 }
@@ -700,11 +704,11 @@ __device__ __forceinline__ void dump_row(const f32x4 (&acc)[Geo<NB>::TPW], float
 }
 
 // LU (default build): the whole solve runs on the accumulators inside the wave roles.
-template <int NB, int MODE, int W>
+template <int NB, int MODE, int W, bool NEG = false>
 __device__ __forceinline__ void finish_row(f32x4 (&acc)[Geo<NB>::TPW], float* smem, const KernelArgs& a, int row,
                                            int rowlen, int tid) {
   if constexpr (MODE == kModeLU && lu_on_accumulators(NB)) {
-    lu_solve_wg<NB, W>(acc, smem, a.f, (float)rowlen * a.lambda, a.update + (size_t)row * a.f, tid, a.sse_bins, rowlen);
+    lu_solve_wg<NB, W, 4, NEG>(acc, smem, a.f, (float)rowlen * a.lambda, a.update + (size_t)row * a.f, tid, a.sse_bins, rowlen);
   } else {
     dump_row<NB, MODE, W>(acc, smem, a, row, rowlen, tid & 63);
   }
@@ -871,12 +875,13 @@ template <int NB, int MODE, int W>
 __device__ __forceinline__ void reduce_body(float* smem, const KernelArgs& a, int row, int slot0, int nslots,
                                             int rowlen, int lane) {
   constexpr int TPW = Geo<NB>::TPW;
+  constexpr bool NEG = MODE == kModeLU && lu_on_accumulators(NB) && lu_wg_blocked(NB);  // the blocked LU eliminates -A
   f32x4 acc[TPW];
 #pragma unroll
   for (int s = 0; s < TPW; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int sl = 0; sl < nslots; ++sl)
-    partial_accumulate<NB, W>(acc, a.part + (size_t)(slot0 + sl) * Geo<NB>::NT * 256, lane);
-  finish_row<NB, MODE, W>(acc, smem, a, row, rowlen, lane + 64 * W);
+    partial_accumulate<NB, W, NEG>(acc, a.part + (size_t)(slot0 + sl) * Geo<NB>::NT * 256, lane);
+  finish_row<NB, MODE, W, NEG>(acc, smem, a, row, rowlen, lane + 64 * W);
 }
 
 // Round 6: the LU of the largest systems (NB = 12, 13: f = 176 .. 207; 164-168 registers = three workgroups per CU) is latency- and
@@ -1672,6 +1677,17 @@ hipError_t launch_half_iteration(const KernelArgs& a, int mode, long n_items, lo
       aw.item_slot = nullptr, aw.item_rowlen = lists->w_rowlen;
       aw.whole_only = 1;
       n_items = lists->n_witems;
+    }
+    // Round 6: the short whole rows of a CG plan (the last n_short items) never form their Gram matrix (als_short.hip)
+    static const bool short_cg_on = !getenv("CUMF_ALS_SHORT_CG") || atoi(getenv("CUMF_ALS_SHORT_CG")) != 0;
+    long n_short = 0;
+    if (mode == kModeCG && short_cg_on && lists != nullptr && short_cg_available(a.f) && !a.dense_slots) n_short = lists->n_short;
+    KernelArgs as = aw;
+    if (n_short > 0) {
+      n_items -= n_short;
+      as.item_row += n_items, as.item_begin += n_items, as.item_len += n_items, as.item_rowlen += n_items;
+      e = launch_short_cg(as, n_short, stream);  // first: the tail of the long items then fills in behind it
+      if (e != hipSuccess) return e;
     }
     switch (nb_for_f(a.f)) {
 #define CUMF_WAVE(N)                                              \

@@ -391,7 +391,7 @@ __host__ __device__ constexpr bool lu_role_in_row(int W, int Ip) {
   return false;
 }
 
-template <int NB, int W, int NW = 4>
+template <int NB, int W, int NW = 4, bool NEGATED = false>
 __device__ __forceinline__ void lu_solve_blocked_wg(LuAcc<NB, NW>& acc, float* __restrict__ lds, int f, float reg,
                                                     float* __restrict__ x_global, int tid, double* sse_bins = nullptr,
                                                     int rowlen = 0) {
@@ -403,17 +403,19 @@ __device__ __forceinline__ void lu_solve_blocked_wg(LuAcc<NB, NW>& acc, float* _
   float* rdiag = Twin + LuBlkLds<NB>::kU;             // 1 / (-u_kk)
   float* ctab = rdiag + ((f + 3) & ~3);               // 2 x 16 floats, 16-byte aligned
   float* zpad = ctab + 32;
-  // the system, negated: -(A + lambda n_u I) (als.cu:545-557 for the diagonal term)
+  // the system, negated: -(A + lambda n_u I) (als.cu:545-557 for the diagonal term); NEGATED: the caller hands over -A
   static_for<TPW>([&](auto sc) {
     constexpr int s = decltype(sc)::value;
     constexpr int t = LuGeo<NB, NW>::tile(W, s);
     if constexpr (t < NT) {
       constexpr bool diag = tile_I<NB>(t) == tile_J<NB>(t);
+      if constexpr (diag || !NEGATED) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = acc[s][r];
-        if constexpr (diag) v = (4 * kk + r == c) ? v + reg : v;
-        acc[s][r] = -v;
+        for (int r = 0; r < 4; ++r) {
+          float v = NEGATED ? -acc[s][r] : acc[s][r];
+          if constexpr (diag) v = (4 * kk + r == c) ? v + reg : v;
+          acc[s][r] = -v;
+        }
       }
     }
   });
@@ -595,11 +597,12 @@ __device__ __forceinline__ void lu_solve_blocked_wg(LuAcc<NB, NW>& acc, float* _
 }
 
 // the LU of the workgroup kernels: blocked from CUMF_WG_LU_BLOCKED_NB feature blocks on
-template <int NB, int W, int NW = 4>
+template <int NB, int W, int NW = 4, bool NEGATED = false>
 __device__ __forceinline__ void lu_solve_wg(LuAcc<NB, NW>& acc, float* __restrict__ lds, int f, float reg,
                                             float* __restrict__ x_global, int tid, double* sse_bins = nullptr, int rowlen = 0) {
+  static_assert(!NEGATED || lu_wg_blocked(NB), "only the blocked elimination takes the negated system");
   if constexpr (lu_wg_blocked(NB))
-    lu_solve_blocked_wg<NB, W, NW>(acc, lds, f, reg, x_global, tid, sse_bins, rowlen);
+    lu_solve_blocked_wg<NB, W, NW, NEGATED>(acc, lds, f, reg, x_global, tid, sse_bins, rowlen);
   else
     lu_solve_mfma<NB, W, NW>(acc, lds, f, reg, x_global, tid, sse_bins, rowlen);
 }

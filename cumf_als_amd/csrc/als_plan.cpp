@@ -36,6 +36,7 @@ struct cumf_plan {
   long long plan_nnz = 0;  // ratings of the planned rows
   long long chunk_nnz = 0;  // ... of which in chunked rows
   long n_items = 0, n_slots = 0, n_mrows = 0;
+  long n_short = 0;  // whole rows of at most kShortRow ratings: the last n_short items (and the last of the w list)
   int* d_item_row = nullptr;
   long long* d_item_begin = nullptr;
   int* d_item_len = nullptr;
@@ -158,11 +159,21 @@ extern "C" int cumf_plan_create(cumf_plan_t** out, const void* rowptr_host, int 
   const size_t n_it = item_row.size();
   std::vector<long> order(n_it);
   static const int order_mode = getenv("CUMF_ALS_ORDER") ? atoi(getenv("CUMF_ALS_ORDER")) : 0;
+  // Round 6: whole rows of at most kShortRow ratings go behind everything else (longest first among themselves): the CG of
+  // als_short.hip takes exactly the last n_short items of a launch; every other kernel treats items independently.
+  long n_short = 0;
   if (order_mode == 0) {
-    std::vector<long> start((size_t)chunk + 2, 0);
-    for (size_t i = 0; i < n_it; ++i) ++start[(size_t)(chunk - item_len[i]) + 1];  // bucket 0 = the longest
+    auto bucket = [&](size_t i) -> size_t {
+      const bool is_short = item_slot[i] < 0 && item_len[i] <= kShortRow;
+      return is_short ? (size_t)chunk + 1 + (size_t)(kShortRow - item_len[i]) : (size_t)(chunk - item_len[i]);
+    };
+    std::vector<long> start((size_t)chunk + kShortRow + 3, 0);
+    for (size_t i = 0; i < n_it; ++i) {
+      ++start[bucket(i) + 1];  // bucket 0 = the longest
+      n_short += item_slot[i] < 0 && item_len[i] <= kShortRow;
+    }
     for (size_t k = 1; k < start.size(); ++k) start[k] += start[k - 1];
-    for (size_t i = 0; i < n_it; ++i) order[(size_t)start[(size_t)(chunk - item_len[i])]++] = (long)i;  // stable
+    for (size_t i = 0; i < n_it; ++i) order[(size_t)start[bucket(i)]++] = (long)i;  // stable
   } else {
     std::iota(order.begin(), order.end(), 0L);
   }
@@ -176,6 +187,7 @@ extern "C" int cumf_plan_create(cumf_plan_t** out, const void* rowptr_host, int 
   p->chunk = chunk;
   p->plan_nnz = rp(row_end) - rp(row_begin);
   p->n_items = (long)n_it;
+  p->n_short = n_short;
   p->n_slots = n_slots;
   p->n_mrows = (long)mrow_row.size();
   for (size_t i = 0; i < n_it; ++i) {
@@ -391,7 +403,7 @@ int plan_lists(const cumf_plan_t* p, PlanLists* out, hipStream_t stream, bool ne
   }
   *out = PlanLists{p->n_items,  p->n_mrows, p->n_citems, p->n_witems, p->d_c_row,    p->d_c_len,  p->d_c_slot,
                    p->d_c_rowlen, p->d_c_begin, p->d_w_row,  p->d_w_len,  p->d_w_rowlen, p->d_w_begin, part2,
-                   rows,          p->plan_nnz > 0 ? (double)p->chunk_nnz / (double)p->plan_nnz : 0.0};
+                   rows,          p->plan_nnz > 0 ? (double)p->chunk_nnz / (double)p->plan_nnz : 0.0, p->n_short};
   return 0;
 }
 
@@ -422,6 +434,7 @@ KernelArgs base_args(const cumf_plan_t* p, const int* colidx, const float* val, 
   a.colidx = colidx;
   a.val = val;
   a.gather = gather;
+  a.gather_f32 = gather;
   a.row_begin = p->row_begin;
   a.f = f;
   a.lambda = lambda;
