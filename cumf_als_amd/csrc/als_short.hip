@@ -17,7 +17,7 @@
 // route (the reference rounds the entries of A first), parity is by the CG tolerance of the tests.  The right-hand side is
 // T^T r, the fused train SSE is S - x.b - x.r - lambda n |x|^2 with S = sum r^2 as in cg_wave_core.
 // Items: the plan lists its short whole rows last (als_plan.cpp); launch_half_iteration hands them to this kernel when the
-// solver is CG and f has an instance (f = 100: BASELINE configs[3]).
+// solver is CG and 32 <= f <= 128 (of the wave kernels' range f <= 111; BASELINE configs[3] is f = 100).
 #include <hip/hip_runtime.h>
 
 #include "als_device.h"
@@ -82,14 +82,14 @@ __device__ __forceinline__ float reduce_transposed(float (&P)[N], int lane) {
   return v + lane_xor<32>(v, lane);
 }
 
-// the whole row with at most N ratings in flight (N = 8, 16, 32 >= n)
-template <int F, int N>
+// the whole row with at most N ratings in flight (N = 8, 16, 32 >= n); TWO: f > 64, the lanes hold two features each
+template <bool TWO, int N>
 __device__ __forceinline__ void short_cg_row(const KernelArgs& a, int row, int n, float rv, const float* grow, int lane) {
-  constexpr int F1 = F - 64;  // features of the second register
-  const bool f1 = lane < F1;
-  float* xg = a.update + (size_t)row * F;
+  const int f = a.f;
+  const bool f0 = lane < f, f1 = TWO && lane + 64 < f;  // this lane's features exist
+  float* xg = a.update + (size_t)row * f;
   // warm start (cg.cu:48)
-  float x0 = xg[lane], x1 = f1 ? xg[64 + lane] : 0.f;
+  float x0 = f0 ? xg[lane] : 0.f, x1 = f1 ? xg[64 + lane] : 0.f;
   // feature layout: one rating at a time, coalesced; ratings past n read the zero row
   float T0[N], T1[N];
   const unsigned long long gaddr = reinterpret_cast<unsigned long long>(grow);
@@ -99,7 +99,7 @@ __device__ __forceinline__ void short_cg_row(const KernelArgs& a, int row, int n
     const unsigned lo = (unsigned)__builtin_amdgcn_readlane(glo, r), hi = (unsigned)__builtin_amdgcn_readlane(ghi, r);
     typedef __attribute__((address_space(1))) const float gfloat;  // global loads, not flat ones
     gfloat* base = reinterpret_cast<gfloat*>(((unsigned long long)hi << 32) | lo);
-    T0[r] = base[lane];
+    T0[r] = f0 ? base[lane] : 0.f;
     T1[r] = f1 ? base[64 + lane] : 0.f;
   });
   const float reg = (float)n * a.lambda;  // lambda * n_u on the diagonal (als.cu:545-557)
@@ -112,7 +112,7 @@ __device__ __forceinline__ void short_cg_row(const KernelArgs& a, int row, int n
           constexpr int r = 4 * q + decltype(ic)::value;
           const float wr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w), r));
           y0 = fmaf(T0[r], wr, y0);
-          y1 = fmaf(T1[r], wr, y1);
+          if constexpr (TWO) y1 = fmaf(T1[r], wr, y1);
         });
       }
     });
@@ -122,13 +122,13 @@ __device__ __forceinline__ void short_cg_row(const KernelArgs& a, int row, int n
     float P[N];
     static_for<N>([&](auto rc) {
       constexpr int r = decltype(rc)::value;
-      P[r] = fmaf(T1[r], v1, T0[r] * v0);
+      P[r] = TWO ? fmaf(T1[r], v1, T0[r] * v0) : T0[r] * v0;
     });
     const float u = reduce_transposed<N>(P, lane);
     y0 = reg * v0, y1 = reg * v1;
     tt_product(u, y0, y1);
   };
-  auto dot = [&](float a0, float a1, float c0, float c1) { return wave_sum_uniform(fmaf(a1, c1, a0 * c0)); };
+  auto dot = [&](float a0, float a1, float c0, float c1) { return wave_sum_uniform(TWO ? fmaf(a1, c1, a0 * c0) : a0 * c0); };
   // right-hand side b = T^T r (als.cu:750-757)
   float b0 = 0.f, b1 = 0.f;
   tt_product(rv, b0, b1);
@@ -150,7 +150,7 @@ __device__ __forceinline__ void short_cg_row(const KernelArgs& a, int row, int n
     rsold = rsnew;
     p0 = fmaf(beta, p0, r0), p1 = fmaf(beta, p1, r1);
   }
-  xg[lane] = x0;
+  if (f0) xg[lane] = x0;
   if (f1) xg[64 + lane] = x1;
   if (a.sse_bins != nullptr) {  // fused train SSE, as cg_wave_core: S - x.b - x.r - reg |x|^2
     const float S = wave_sum_uniform(rv * rv);
@@ -160,9 +160,8 @@ __device__ __forceinline__ void short_cg_row(const KernelArgs& a, int row, int n
   }
 }
 
-template <int F>
+template <bool TWO>
 __global__ __launch_bounds__(64, 4) void als_short_cg_kernel(const KernelArgs a) {
-  static_assert(F % 4 == 0 && F > 64 && F <= 128, "two feature registers per lane");
   static_assert(kShortRow == 32, "ratings per row at most");
   const int lane = threadIdx.x;
   const int item = blockIdx.x;
@@ -172,24 +171,29 @@ __global__ __launch_bounds__(64, 4) void als_short_cg_kernel(const KernelArgs a)
   const bool live = lane < n;
   const int j = live ? a.colidx[begin + lane] : 0;
   const float rv = live ? a.val[begin + lane] : 0.f;
-  const float* grow = live ? a.gather_f32 + (size_t)j * F : g_short_zeros;
+  const float* grow = live ? a.gather_f32 + (size_t)j * a.f : g_short_zeros;
   if (n <= 8)
-    short_cg_row<F, 8>(a, row, n, rv, grow, lane);
+    short_cg_row<TWO, 8>(a, row, n, rv, grow, lane);
   else if (n <= 16)
-    short_cg_row<F, 16>(a, row, n, rv, grow, lane);
+    short_cg_row<TWO, 16>(a, row, n, rv, grow, lane);
   else
-    short_cg_row<F, 32>(a, row, n, rv, grow, lane);
+    short_cg_row<TWO, 32>(a, row, n, rv, grow, lane);
 }
 
 }  // namespace
 
-bool short_cg_available(int f) { return f == 100; }
+// any f of the wave kernels' range up to two features per lane (the factored mat-vec costs 2 n f against f^2: it pays from
+// f = 32 on for every n <= 32)
+bool short_cg_available(int f) { return f >= 32 && f <= 128; }
 
 // items [0, n_items) of the lists in `a` (the caller has advanced the list pointers to the plan's short rows)
 hipError_t launch_short_cg(const KernelArgs& a, long n_items, hipStream_t stream) {
   if (n_items <= 0) return hipSuccess;
-  if (a.f != 100) return hipErrorInvalidValue;
-  hipLaunchKernelGGL((als_short_cg_kernel<100>), dim3((unsigned)n_items), dim3(64), 0, stream, a);
+  if (!short_cg_available(a.f)) return hipErrorInvalidValue;
+  if (a.f > 64)
+    hipLaunchKernelGGL((als_short_cg_kernel<true>), dim3((unsigned)n_items), dim3(64), 0, stream, a);
+  else
+    hipLaunchKernelGGL((als_short_cg_kernel<false>), dim3((unsigned)n_items), dim3(64), 0, stream, a);
   return hipGetLastError();
 }
 

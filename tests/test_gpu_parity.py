@@ -607,6 +607,65 @@ def test_fused_half_iteration(oracle, alslib, gram_mode, solver, f):
                 assert e_h <= 2.0 * e_o + 1e-5, (chunk, err, e_h, e_o)
 
 
+@pytest.mark.parametrize("f", [32, 48, 64, 100, 110])
+def test_short_rows_gram_free_cg(oracle, alslib, f):
+    """Round 6 (als_short.hip): whole rows of at most 32 ratings run the reference's CG (cg.cu:36-231) on A = T^T T + lambda n I
+    without forming A -- u = T p by a transposing wave reduction, y = T^T u by broadcasts.  Rows of every length around
+    the kernel's internal sizes (8 / 16 / 32 ratings in flight), an empty row, and rows just above the limit (Gram route) in ONE
+    plan: NaN pattern of the reference (cg.cu:128), per row no further from the fp64 iterate than twice the fp32 oracle is
+    (the full-size tests' yardstick; measured: closer than the Gram route), and the fused train SSE -- S - x.b - x.r -
+    lambda n |x|^2 from the kernel's own vectors -- equal to the fp64 sum over the ratings on the returned factors."""
+    _need_gpu()
+    from cumf_als_amd import als, datagen
+
+    lens = [0, 1, 2, 3, 4, 5, 7, 8, 9, 12, 15, 16, 17, 20, 24, 25, 31, 32, 33, 40, 64, 65, 100] * 3
+    n_cols = 160
+    rng = np.random.RandomState(11)
+    rows, cols, vals = [], [], []
+    for u, ln in enumerate(lens):
+        c = np.sort(rng.choice(n_cols, ln, replace=False))
+        rows += [u] * ln
+        cols += c.tolist()
+        vals += rng.randint(1, 6, ln).astype(np.float32).tolist()
+    r = datagen.from_coo(len(lens), n_cols, rows, cols, vals, [0], [0], [1.0])
+    d = r.numpy()
+    theta = _factors(n_cols, f, 5)
+    x0 = _factors(len(lens), f, 6) * 0.05
+    lam = 0.05
+    x32 = oracle.half_iteration(d["csr_indptr"], d["csr_indices"], d["csr_data"], theta, x0.copy(), f, lam, solver="cg")
+    x64 = oracle.half_iteration(d["csr_indptr"], d["csr_indices"], d["csr_data"], theta, x0.copy(), f, lam, solver="cg",
+                                dtype=np.float64)
+    rg = r.to("cuda")
+    plan = als.Plan(d["csr_indptr"], f)
+    x = torch.from_numpy(x0.copy()).cuda()
+    bins = als.update_fused_sse(plan, rg.csr_indices, rg.csr_data, torch.from_numpy(theta).cuda(), x, lam, "cg", 6)
+    torch.cuda.synchronize()
+    xh = x.cpu().numpy()
+    assert np.array_equal(np.isnan(xh), np.isnan(x64)) and np.isnan(xh[0]).all()
+    fin = ~np.isnan(x64).any(1)
+    e_o = np.abs(x32[fin] - x64[fin]).max(1)
+    e_h = np.abs(xh[fin] - x64[fin]).max(1)
+    scale = np.abs(x64[fin]).max()
+    # two fp32 evaluations of six CG steps differ row by row (rows of fewer ratings than features: the recurrence divides
+    # rounding noise by rounding noise once the n + 1 steps that solve the row are over), so the comparison is between the
+    # DISTRIBUTIONS over the rows, as in tests/test_gpu_fullsize.py: median, 90th percentile and maximum of the distance from
+    # the fp64 iterate no larger than the fp32 oracle's own, + 1e-5 of the factors' scale
+    stats = lambda v: (float(np.median(v)), float(np.quantile(v, 0.9)), float(v.max()))
+    short = np.asarray(lens)[fin] <= 32
+    print(f"short rows f={f}: |x - x64| (median, q90, max) hip {stats(e_h[short])} oracle32 {stats(e_o[short])}; "
+          f"longer rows hip {stats(e_h[~short])} oracle32 {stats(e_o[~short])}")
+    for sh, so in zip(stats(e_h[short]), stats(e_o[short])):
+        assert sh <= 1.05 * so + 1e-5 * scale, (f, stats(e_h[short]), stats(e_o[short]))
+    # train SSE of the finite rows on the returned factors, fp64
+    ptr, idx, val = d["csr_indptr"], d["csr_indices"], d["csr_data"].astype(np.float64)
+    sse = 0.0
+    for u in np.nonzero(fin)[0]:
+        pred = theta[idx[ptr[u]:ptr[u + 1]]].astype(np.float64) @ xh[u].astype(np.float64)
+        sse += float(((val[ptr[u]:ptr[u + 1]] - pred) ** 2).sum())
+    got = float(bins.sum().item())
+    assert abs(got - sse) <= 2e-5 * sse, (got, sse)
+
+
 def test_empty_row_gives_nan_like_reference(oracle, alslib):
     """cg.cu:128: alpha = 0/0 on an all-zero system -> NaN factors (same in the oracle)."""
     _need_gpu()
