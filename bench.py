@@ -358,6 +358,14 @@ def make_slab_engine(a, shp, world, rank, dev, f, lam, theta0, solver, cg_iters,
     nnz_slab = max(int(shp["nnz"] * s * s) // 8, m_slab + n)
     r = datagen.synth_ratings(m_slab, n, nnz_slab, 4096, seed=a.seed + 1000 * (rank + 1), device=dev, col_seed=a.seed)
     m, nnz = m_slab * world, nnz_slab * world
+    return slab_engine(a, r, m, n, world, dev, f, lam, theta0, solver, cg_iters, theta_batch), r, m, nnz
+
+
+def slab_engine(a, r, m, n, world, dev, f, lam, theta0, solver, cg_iters, theta_batch):
+    """The `reduce`-scheme engine over one rank's slab `r` (native half-iterations or torch.distributed collectives:
+    whatever cumf_als_amd.dist.set_native / CUMF_DIST_NATIVE selects at this moment)."""
+    from cumf_als_amd import dist as cdist
+
     xb = np.arange(world + 1, dtype=np.int64) * r.m
     # THETA_BATCH = 3 as the reference's hugewiki run (hugewiki.cu:27-41): with more than one rank the
     # reduce-scatter of batch b runs under the partial-Gram pass of batch b + 1
@@ -368,7 +376,7 @@ def make_slab_engine(a, shp, world, rank, dev, f, lam, theta0, solver, cg_iters,
                                         solver=solver, cg_iters=cg_iters,
                                         theta_batch=theta_batch if theta_batch > 0 else (3 if world > 1 else 1), **sides)
     eng.init_factors(theta0)
-    return eng, r, m, nnz
+    return eng
 
 
 def hugewiki_prepare(a, datagen, dev, world, rank):
@@ -380,24 +388,30 @@ def hugewiki_prepare(a, datagen, dev, world, rank):
     g.manual_seed(a.seed)
     theta0 = (0.2 * torch.rand((n, f), generator=g, dtype=torch.float32)).numpy()
     t0 = time.time()
-    eng, r, m, nnz = make_slab_engine(a, shp, world, rank, dev, f, lam, theta0, "cg", 6, a.theta_batch)
+    from cumf_als_amd import dist as cdist
+
+    cdist.set_native(False)  # first with torch.distributed collectives; hugewiki_run then repeats it on the native path
+    try:
+        eng, r, m, nnz = make_slab_engine(a, shp, world, rank, dev, f, lam, theta0, "cg", 6, a.theta_batch)
+    finally:
+        cdist.set_native(None)
     torch.cuda.synchronize()
-    return eng, r, m, nnz, n, f, lam, time.time() - t0
+    return eng, r, m, nnz, n, f, lam, time.time() - t0, theta0
 
 
-def hugewiki_run(a, als, state, dev, world, backend, steps=3):
-    """The collective part of the hugewiki leg (every rank: it holds collectives)."""
+def timed_steps(eng, dev, backend, steps, warmup=1):
+    """`steps` iterations of a distributed engine under the bench's timing rule (barrier + synchronize on both sides, MAX
+    over ranks) -> seconds.  Every rank."""
     import torch.distributed as dist
-
-    eng, r, m, nnz, n, f, lam, t_gen = state
 
     def barrier():
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
 
-    eng.update_x()
-    eng.update_theta()
+    for _ in range(warmup):
+        eng.update_x()
+        eng.update_theta()
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -406,22 +420,114 @@ def hugewiki_run(a, als, state, dev, world, backend, steps=3):
     barrier()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    diag = rank_diagnostics(eng, als, dev, world, backend, steps=2)
+    return float(t.item())
+
+
+def promote_native(res: dict, nat: dict, keys) -> None:
+    """The native path is the product's default: when its leg came through, its numbers become the object's own and the
+    torch.distributed ones move under "torch_collectives"; a failed native leg stays as "native": {"error": ...} beside the
+    torch.distributed numbers."""
+    if "error" in nat:
+        res["collectives"] = "torch.distributed"
+        res["native"] = nat
+        return
+    res["torch_collectives"] = {k: res[k] for k in keys if k in res}
+    res.update({k: nat[k] for k in keys if k in nat})
+    res["collectives"] = "native (cumf_dist_*, als_dist.cpp: kernels and collectives enqueued from C++)"
+    res["native_equals_torch_collectives"] = nat.get("factors_equal")
+
+
+HW_KEYS = ("value", "ms_per_step", "x_half_ms", "theta_half_ms", "non_kernel_ms", "per_rank")
+
+
+def hugewiki_run(a, als, state, dev, world, backend, steps=3, guard=None):
+    """The collective part of the hugewiki leg (every rank: it holds collectives): the engine with torch.distributed
+    collectives first (its numbers are in the guard's line before anything else is tried), then the same slab on the native
+    half-iterations (cumf_dist_reduce_update_theta), which take the object over when they come through."""
+    import torch.distributed as dist
+
+    from cumf_als_amd import dist as cdist
+
+    eng, r, m, nnz, n, f, lam, t_gen, theta0 = state
+
+    def measure(e):
+        elapsed = timed_steps(e, dev, backend, steps)
+        diag = rank_diagnostics(e, als, dev, world, backend, steps=2)
+        return {"value": 2.0 * nnz * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps,
+                "x_half_ms": diag["max_over_ranks"]["x_half_ms"], "theta_half_ms": diag["max_over_ranks"]["theta_half_ms"],
+                "non_kernel_ms": {"x": diag["max_over_ranks"]["x_non_kernel_ms"],
+                                  "theta": diag["max_over_ranks"]["theta_non_kernel_ms"]},
+                "per_rank": diag["per_rank"]}
+
     theta_batches = len(eng.t_batches)
+    res = {"unit": "ratings/s", "steps": steps, "warmup": 1, "scaling": "weak", "n_ranks_seen": dist.get_world_size(),
+           "scheme": "reduce", "theta_batch": theta_batches, "solver": "cg(6)",
+           "workload": f"hugewiki-shape synthetic ratings {m}x{n}, nnz={nnz}, f={f}, lambda={lam}: one 1/8 row slab "
+                       f"({r.m} rows, {r.nnz} ratings) per GPU (BASELINE.json configs[3])",
+           "gen_seconds": round(t_gen, 2), "collectives": "torch.distributed"}
+    res.update(measure(eng))
+    eng.init_factors(theta0)
+    eng.iterate(1)
+    th_t, x_t = eng.thetaT.clone(), eng.XT.clone()
     eng.close()
-    return {"value": 2.0 * nnz * steps / elapsed, "unit": "ratings/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
-            "warmup": 1, "scaling": "weak", "n_ranks_seen": dist.get_world_size(), "scheme": "reduce",
-            "theta_batch": theta_batches, "solver": "cg(6)",
-            "workload": f"hugewiki-shape synthetic ratings {m}x{n}, nnz={nnz}, f={f}, lambda={lam}: one 1/8 row slab "
-                        f"({r.m} rows, {r.nnz} ratings) per GPU (BASELINE.json configs[3])",
-            "gen_seconds": round(t_gen, 2),
-            "x_half_ms": diag["max_over_ranks"]["x_half_ms"], "theta_half_ms": diag["max_over_ranks"]["theta_half_ms"],
-            "non_kernel_ms": {"x": diag["max_over_ranks"]["x_non_kernel_ms"], "theta": diag["max_over_ranks"]["theta_non_kernel_ms"]},
-            "per_rank": diag["per_rank"]}
+    del eng
+    if guard is not None:
+        guard.note(lambda line: line.__setitem__("hugewiki", dict(res)))
+        guard.pending = ("hugewiki", "native")
+    nat = native_leg(lambda: slab_engine(a, r, m, n, world, dev, f, lam, theta0, "cg", 6, a.theta_batch), measure,
+                     theta0, (th_t, x_t), dev, world, dist.get_rank(), backend)
+    promote_native(res, nat, HW_KEYS)
+    return res
 
 
-def hugewiki_leg(a, als, datagen, dev, world, rank, backend, steps=3):
+def native_leg(make_engine, measure, theta0, torch_factors, dev, world, rank, backend):
+    """One engine on the native half-iterations (als_dist.cpp), measured by `measure`, and checked against the factors the
+    torch.distributed engine produced in one iteration from the same start (same kernels, same plans: bit-identical).  A
+    local failure is agreed on with ONE all-reduce before the leg's first collective; CUMF_BENCH_FAIL_NATIVE=<rank> /
+    hang<rank> injects one (tests).  Returns the measured object or {"error": ...}; every rank."""
+    import torch.distributed as dist
+
+    from cumf_als_amd import dist as cdist
+
+    err = None
+    try:
+        if os.environ.get("CUMF_BENCH_FAIL_NATIVE") == str(rank):
+            raise RuntimeError(f"injected failure on rank {rank} (CUMF_BENCH_FAIL_NATIVE)")
+        if os.environ.get("CUMF_BENCH_FAIL_NATIVE") == f"hang{rank}":
+            time.sleep(1e6)
+    except BaseException as e:  # noqa: BLE001
+        err = f"rank {rank}: {type(e).__name__}: {e}"
+    ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+        return {"error": err or "another rank failed before the native leg"}
+    eng = None
+    try:
+        cdist.set_native(True)
+        eng = make_engine()
+        if eng._ncomm is None:
+            raise RuntimeError("the engine did not take the native path")
+        nat = measure(eng)
+        nat["transport"] = eng._ncomm.name
+        eng.init_factors(theta0)
+        eng.iterate(1)
+        same = torch.equal(eng.thetaT, torch_factors[0]) and torch.equal(eng.XT, torch_factors[1])
+        diff = max(float((eng.thetaT - torch_factors[0]).abs().nan_to_num(0.0).max().item()) if eng.thetaT.numel() else 0.0,
+                   float((eng.XT - torch_factors[1]).abs().nan_to_num(0.0).max().item()) if eng.XT.numel() else 0.0)
+        flag = torch.tensor([1.0 if same else 0.0, -diff], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        nat["factors_equal"] = bool(int(flag[0].item()))
+        nat["factors_max_abs_diff"] = -float(flag[1].item())
+        return nat
+    except Exception as e:  # noqa: BLE001 -- symmetric failures (an RCCL error on every rank); a hang is the guard's
+        return {"error": f"rank {rank}: {type(e).__name__}: {e}"}
+    finally:
+        cdist.set_native(None)
+        if eng is not None:
+            eng.close()
+
+
+def hugewiki_leg(a, als, datagen, dev, world, rank, backend, steps=3):  # noqa: D401
     """N > 1: north_star's ">= 6 x at 8 GPUs" is stated on the hugewiki-scale synthetic shape
     (hugewiki.cu:27-41: weak scaling, one 1/8 row slab per GPU, X row-sharded, partial Grams reduce-scattered over RCCL),
     while the default N > 1 line is the Netflix shape (strong scaling).  This leg runs the slab configuration right behind
@@ -449,6 +555,9 @@ class LineGuard:
         self.line, self.deadline_s = line, deadline_s + (0.0 if line is not None else 10.0)
         self._lock = threading.Lock()
         self._done = False
+        # where an error lands when the deadline passes: the key path of the leg that is running, e.g. ("native",),
+        # ("hugewiki",), ("hugewiki", "native") -- what earlier legs left in the line (`note`) stays
+        self.pending = ("hugewiki",)
         self._rd, self._wr = os.pipe()
         os.set_blocking(self._wr, False)
         try:
@@ -459,13 +568,24 @@ class LineGuard:
         self._thread = threading.Thread(target=self._watch, daemon=True)
         self._thread.start()
 
-    def _print(self, extra) -> bool:
+    def note(self, fn) -> None:
+        """A finished leg records its result in the line (under the lock: the watcher may be printing)."""
+        with self._lock:
+            if not self._done and self.line is not None:
+                fn(self.line)
+
+    def _print(self, extra, why=None) -> bool:
         with self._lock:
             if self._done:
                 return False
             self._done = True
             if self.line is not None:
-                if extra is not None:
+                if why is not None:
+                    d = self.line
+                    for k in self.pending[:-1]:
+                        d = d.setdefault(k, {})
+                    d[self.pending[-1]] = {"error": why}
+                elif extra is not None:
                     self.line["hugewiki"] = extra
                 print(json.dumps(self.line), flush=True)
             return True
@@ -476,7 +596,7 @@ class LineGuard:
         ready, _, _ = select.select([self._rd], [], [], self.deadline_s)
         why = ("terminated by the launcher (another rank failed)" if ready
                else f"no result after {self.deadline_s:.0f} s (collective hang?)")
-        self._print({"error": why})  # no-op when the line is already out
+        self._print(None, why)  # no-op when the line is already out
         sys.stdout.flush()
         os._exit(0)
 
@@ -484,7 +604,7 @@ class LineGuard:
         self._print(extra)
 
 
-def hugewiki_leg_guarded(a, als, datagen, dev, world, rank, backend):
+def hugewiki_leg_guarded(a, als, datagen, dev, world, rank, backend, guard=None):
     """`hugewiki_leg` so that no rank's failure takes the line down: the local part (slab generation, engine construction:
     no collective) runs under try / except on every rank and the ranks agree on the outcome with ONE all-reduce (MIN) before
     the first collective of the leg; the collective part runs under try / except too (symmetric failures: an RCCL error)
@@ -508,7 +628,7 @@ def hugewiki_leg_guarded(a, als, datagen, dev, world, rank, backend):
             state[0].close()
         return {"error": err or "another rank failed while preparing its slab"}
     try:
-        return hugewiki_run(a, als, state, dev, world, backend)
+        return hugewiki_run(a, als, state, dev, world, backend, guard=guard)
     except Exception as e:  # noqa: BLE001
         return {"error": f"rank {rank}: {type(e).__name__}: {e}"}
 
@@ -555,6 +675,8 @@ def main() -> int:
     ap.add_argument("--reference-solvers", action="store_true",
                     help="--shape hugewiki: X by CG(100), Theta by LU, as the reference's hugewiki run (hugewiki.cu:2569,2732)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-native-leg", action="store_true",
+                    help="N > 1: keep the line on torch.distributed collectives (skip the native half-iterations behind it)")
     ap.add_argument("--no-hugewiki-leg", action="store_true",
                     help="N > 1: skip the hugewiki-slab leg (weak scaling, reduce scheme) behind the default Netflix one")
     ap.add_argument("--no-rmse-log", action="store_true",
@@ -654,22 +776,33 @@ def main() -> int:
 
         from cumf_als_amd import dist as cdist
 
-        if a.scheme == "gather":
-            # every rank generates the same matrix on its own GPU (same seed) and keeps zero-copy views
-            # of its row / column slabs: nothing travels through host memory
-            eng = cdist.DistALS.from_device_ratings(r, f, lam, cdist.HipOps(dev), solver=a.solver, cg_iters=a.cg_iters)
-        else:
-            # reduce scheme on a shape whose factors would fit one GPU: every rank keeps zero-copy views of ITS row slab
-            # of the device-resident matrix (only the row pointer visits the host); the slab-local CSC is built on the
-            # device (from_local_slab), as for the hugewiki slabs
-            rp = r.csr_indptr.cpu().numpy().astype(np.int64)
-            xb = cdist.balanced_slabs(rp, world, cdist.solve_row_cost(f, a.solver))
-            x0, x1 = int(xb[rank]), int(xb[rank + 1])
-            rowptr_l = torch.from_numpy(rp[x0:x1 + 1] - rp[x0]).to(dev)
-            eng = cdist.DistALS.from_local_slab(m, n, xb, rowptr_l, r.csr_indices[rp[x0]:rp[x1]], r.csr_data[rp[x0]:rp[x1]],
-                                                f, lam, cdist.HipOps(dev), solver=a.solver, cg_iters=a.cg_iters,
-                                                theta_batch=a.theta_batch if a.theta_batch > 0 else 3)
-        eng.init_factors(theta0)
+        def make_engine():
+            if a.scheme == "gather":
+                # every rank generates the same matrix on its own GPU (same seed) and keeps zero-copy views
+                # of its row / column slabs: nothing travels through host memory
+                e = cdist.DistALS.from_device_ratings(r, f, lam, cdist.HipOps(dev), solver=a.solver, cg_iters=a.cg_iters)
+            else:
+                # reduce scheme on a shape whose factors would fit one GPU: every rank keeps zero-copy views of ITS row slab
+                # of the device-resident matrix (only the row pointer visits the host); the slab-local CSC is built on the
+                # device (from_local_slab), as for the hugewiki slabs
+                rp = r.csr_indptr.cpu().numpy().astype(np.int64)
+                xb = cdist.balanced_slabs(rp, world, cdist.solve_row_cost(f, a.solver))
+                x0, x1 = int(xb[rank]), int(xb[rank + 1])
+                rowptr_l = torch.from_numpy(rp[x0:x1 + 1] - rp[x0]).to(dev)
+                e = cdist.DistALS.from_local_slab(m, n, xb, rowptr_l, r.csr_indices[rp[x0]:rp[x1]], r.csr_data[rp[x0]:rp[x1]],
+                                                  f, lam, cdist.HipOps(dev), solver=a.solver, cg_iters=a.cg_iters,
+                                                  theta_batch=a.theta_batch if a.theta_batch > 0 else 3)
+            e.init_factors(theta0)
+            return e
+
+        # The line is first measured with torch.distributed collectives driven from Python (rounds 1-5: the conservative
+        # path) and handed to the LineGuard; the native half-iterations (als_dist.cpp, the product's default) are measured
+        # behind it under the guard and take the line over when they come through.
+        cdist.set_native(False)
+        try:
+            eng = make_engine()
+        finally:
+            cdist.set_native(None)
 
         def step(timed):
             eng.update_x()
@@ -732,14 +865,43 @@ def main() -> int:
         # it under a guard that prints the line -- with hugewiki: {"error": ...} -- if the leg hangs or the launcher tears
         # the job down; a failure inside the leg comes back as the same object (every rank: the leg holds collectives).
         guard = LineGuard(out, float(os.environ.get("CUMF_BENCH_LEG_DEADLINE", "600")))
+        if not slab_mode and not a.no_native_leg:
+            # the same K steps on the native half-iterations; one iteration from theta0 on both engines for the factors
+            guard.pending = ("native",)
+            eng.init_factors(theta0)
+            eng.iterate(1)
+            factors_t = (eng.thetaT.clone(), eng.XT.clone())
+
+            def measure(e):
+                elapsed_n = timed_steps(e, dev, backend, a.steps, a.warmup)
+                d = rank_diagnostics(e, als, dev, world, backend)
+                return {"value": 2.0 * nnz * a.steps / elapsed_n, "ms_per_step": 1e3 * elapsed_n / a.steps,
+                        "ranks": {"per_rank": d["per_rank"], "max_over_ranks": d["max_over_ranks"],
+                                  "steps_averaged": d["steps_averaged"]}}
+
+            nat = native_leg(make_engine, measure, theta0, factors_t, dev, world, rank, backend)
+
+            def take_over(line):
+                if "error" not in nat:  # rank 0's line: the diagnostics of the path whose numbers it carries
+                    ranks_t = {k: line["ranks"].pop(k) for k in ("per_rank", "max_over_ranks", "steps_averaged")}
+                    line["ranks"].update(nat.pop("ranks"))
+                    line["ranks"]["transport"] = nat.pop("transport")
+                    promote_native(line, nat, ("value", "ms_per_step"))
+                    line["torch_collectives"]["ranks"] = ranks_t
+                else:
+                    promote_native(line, nat, ())
+
+            guard.note(take_over)
+            del factors_t
         hw = None
         if not slab_mode and not a.no_hugewiki_leg:
+            guard.pending = ("hugewiki",)
             close = getattr(eng, "close", None)
             if close is not None:
                 close()
             del eng, r
             torch.cuda.empty_cache()
-            hw = hugewiki_leg_guarded(a, als, datagen, dev, world, rank, backend)
+            hw = hugewiki_leg_guarded(a, als, datagen, dev, world, rank, backend, guard=guard)
         guard.emit(hw)
         try:
             dist.destroy_process_group()

@@ -302,6 +302,222 @@ def all_gather_equal(out: torch.Tensor, mine: torch.Tensor, group=None) -> None:
 
 
 # ----------------------------------------------------------------------------------------
+# the native half-iterations (include/cumf_dist_capi.h, csrc/als_dist.cpp): kernels and collectives enqueued back to
+# back from C++ -- no Python between a kernel and its collective.  The classes below only hold the handles.
+# ----------------------------------------------------------------------------------------
+
+_NATIVE = None  # set_native(): True / False override the environment, None = CUMF_DIST_NATIVE (default on)
+
+
+def set_native(flag) -> None:
+    """Engines constructed from now on: True = the native half-iterations, False = torch.distributed collectives driven from
+    Python (the A/B of bench.py and the tests), None = environment CUMF_DIST_NATIVE (default 1)."""
+    global _NATIVE
+    _NATIVE = flag
+
+
+def native_wanted(ops) -> bool:
+    """The native path is the product path of `HipOps`; stand-in ops (CPU tests) have no kernels to enqueue."""
+    import os
+
+    if not isinstance(ops, HipOps):
+        return False
+    return _NATIVE if _NATIVE is not None else os.environ.get("CUMF_DIST_NATIVE", "1") != "0"
+
+
+class _TorchTransport:
+    """`cumf_transport_t` over a torch.distributed group that cannot take device buffers (gloo: the 2-processes-on-one-GPU
+    tests): the callbacks synchronise the communication stream, stage through the host, and return with the result in
+    `recv`.  With the "nccl" backend the native layer owns an RCCL communicator instead (`NativeComm`)."""
+
+    def __init__(self, group):
+        import ctypes as C
+
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        self.error = None
+        ag_t = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+        rs_t = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+        ar_t = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+        class Transport(C.Structure):
+            _fields_ = [("ctx", C.c_void_p), ("all_gather", ag_t), ("reduce_scatter_f32", rs_t), ("all_reduce_f64", ar_t)]
+
+        self._cbs = (ag_t(self._guard(self._all_gather)), rs_t(self._guard(self._reduce_scatter)),
+                     ar_t(self._guard(self._all_reduce)))  # kept alive with the object
+        self.struct = Transport(None, *self._cbs)
+
+    def _guard(self, fn):
+        def wrapped(*args):
+            try:
+                fn(*args)
+                return 0
+            except Exception as e:  # an exception must not unwind through the C frames
+                self.error = e
+                return 1
+        return wrapped
+
+    def _d2h(self, ptr, nbytes, stream) -> torch.Tensor:
+        host = torch.empty(nbytes, dtype=torch.uint8)
+        if self.hip.hipStreamSynchronize(stream) or self.hip.hipMemcpy(host.data_ptr(), ptr, nbytes, 2):
+            raise RuntimeError("hipMemcpy device -> host failed")
+        return host
+
+    def _h2d(self, ptr, host: torch.Tensor) -> None:
+        if self.hip.hipMemcpy(ptr, host.data_ptr(), host.numel() * host.element_size(), 1):
+            raise RuntimeError("hipMemcpy host -> device failed")
+
+    def _all_gather(self, ctx, send, recv, nbytes, stream):
+        mine = self._d2h(send, nbytes, stream)
+        out = torch.empty(self.world * nbytes, dtype=torch.uint8)
+        dist.all_gather_into_tensor(out, mine, group=self.group)
+        self._h2d(recv, out)
+
+    def _reduce_scatter(self, ctx, send, recv, count, stream):
+        full = self._d2h(send, self.world * count * 4, stream).view(torch.float32)
+        dist.all_reduce(full, group=self.group)  # gloo has no reduce_scatter
+        self._h2d(recv, full[self.rank * count:(self.rank + 1) * count].contiguous())
+
+    def _all_reduce(self, ctx, buf, count, stream):
+        v = self._d2h(buf, count * 8, stream).view(torch.float64)
+        dist.all_reduce(v, group=self.group)
+        self._h2d(buf, v)
+
+
+class NativeComm:
+    """`cumf_comm_t` of this rank: an RCCL communicator of its own when the group's backend is "nccl" (the id travels by
+    one broadcast), device copies without a process group, the host-staged `_TorchTransport` otherwise."""
+
+    def __init__(self, device, group=None):
+        import ctypes as C
+
+        from . import lib as _libmod
+
+        self.lib = _libmod.load()
+        self.check = _libmod.check
+        self._h = C.c_void_p()
+        self.transport = None
+        torch.cuda.set_device(device)
+        if not dist.is_initialized():
+            self.check(self.lib.cumf_comm_create_local(C.byref(self._h)), "cumf_comm_create_local")
+        elif dist.get_backend(group) == "nccl":
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+            ident = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                self.check(self.lib.cumf_comm_unique_id(C.c_void_p(ident.data_ptr())), "cumf_comm_unique_id")
+            ident = ident.to(device)
+            dist.broadcast(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            ident = ident.cpu()
+            self.check(self.lib.cumf_comm_create(C.byref(self._h), C.c_void_p(ident.data_ptr()), rank, world),
+                       "cumf_comm_create")
+        else:
+            self.transport = _TorchTransport(group)
+            self.check(self.lib.cumf_comm_create_custom(C.byref(self._h), C.byref(self.transport.struct),
+                                                        self.transport.rank, self.transport.world),
+                       "cumf_comm_create_custom")
+        self.name = self.lib.cumf_comm_transport_name(self._h).decode()
+
+    def checked(self, rc: int, what: str) -> None:
+        if rc != 0 and self.transport is not None and self.transport.error is not None:
+            err, self.transport.error = self.transport.error, None
+            raise RuntimeError(f"{what}: transport callback failed") from err
+        self.check(rc, what)
+
+    def all_reduce_f64(self, t: torch.Tensor) -> torch.Tensor:
+        """Sum a contiguous fp64 device tensor over the ranks, in place, stream-ordered."""
+        import ctypes as C
+
+        assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
+        self.checked(self.lib.cumf_comm_all_reduce_f64(self._h, C.c_void_p(t.data_ptr()), t.numel(),
+                                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                     "cumf_comm_all_reduce_f64")
+        return t
+
+    def close(self) -> None:
+        if self._h:
+            self.lib.cumf_comm_destroy(self._h)
+            self._h = None
+
+
+def _plan_array(plans):
+    import ctypes as C
+
+    return (C.c_void_p * len(plans))(*[p._h if p is not None else None for p in plans])
+
+
+class NativeGather:
+    """One side of the `gather` scheme (`cumf_dist_gather_*`): this rank's slab in pieces, the all-gather of piece c under
+    the kernel of piece c + 1, all enqueued by one C call."""
+
+    def __init__(self, comm: NativeComm, pb: np.ndarray, piece_plans, f: int, gather_rows: int):
+        import ctypes as C
+
+        self.comm, self.f = comm, f
+        pb = np.ascontiguousarray(pb, dtype=np.int64)
+        self.pieces = pb.shape[1] - 1
+        self.plans = list(piece_plans)
+        for p in self.plans:
+            if p is not None:  # the pre-split gather table of cache-resident sides needs the table's row count
+                comm.check(comm.lib.cumf_plan_set_gather_rows(p._h, int(gather_rows)), "cumf_plan_set_gather_rows")
+        self._arr = _plan_array(self.plans)
+        self._h = C.c_void_p()
+        comm.check(comm.lib.cumf_dist_gather_create(C.byref(self._h), comm._h, pb.ctypes.data_as(C.c_void_p), self.pieces, f),
+                   "cumf_dist_gather_create")
+
+    def update(self, colidx, val, table, out, lam, solver, cg_iters, sse_bins=None) -> None:
+        import ctypes as C
+
+        from .als import _dp, _solver_id
+
+        self.comm.checked(self.comm.lib.cumf_dist_gather_update(
+            self._h, self._arr, _dp(colidx, torch.int32), _dp(val, torch.float32), _dp(table, torch.float32),
+            _dp(out, torch.float32), float(lam), _solver_id(solver), int(cg_iters),
+            _dp(sse_bins, torch.float64) if sse_bins is not None else None,
+            C.c_void_p(torch.cuda.current_stream().cuda_stream)), "cumf_dist_gather_update")
+
+    def close(self) -> None:
+        if self._h:
+            self.comm.lib.cumf_dist_gather_destroy(self._h)
+            self._h = None
+
+
+class NativeReduce:
+    """The Theta update of the `reduce` scheme (`cumf_dist_reduce_*`): partial Grams -> reduce-scatter -> solve ->
+    all-gather per Theta batch, pipelined over the batches, one C call per update."""
+
+    def __init__(self, comm: NativeComm, n: int, f: int, batch_plans):
+        import ctypes as C
+
+        self.comm = comm
+        self.plans = list(batch_plans)
+        self._arr = _plan_array(self.plans)
+        self._h = C.c_void_p()
+        comm.check(comm.lib.cumf_dist_reduce_create(C.byref(self._h), comm._h, int(n), int(f), len(self.plans)),
+                   "cumf_dist_reduce_create")
+
+    def update_theta(self, lc_rowidx, lc_val, XT, thetaT, lam, solver, cg_iters, reg_all=None, terms=None) -> None:
+        import ctypes as C
+
+        from .als import _dp, _solver_id
+
+        self.comm.checked(self.comm.lib.cumf_dist_reduce_update_theta(
+            self._h, self._arr, _dp(lc_rowidx, torch.int32), _dp(lc_val, torch.float32), _dp(XT, torch.float32),
+            _dp(thetaT, torch.float32), float(lam), _solver_id(solver), int(cg_iters),
+            _dp(reg_all, torch.float32) if reg_all is not None else None,
+            _dp(terms, torch.float64) if terms is not None else None,
+            C.c_void_p(torch.cuda.current_stream().cuda_stream)), "cumf_dist_reduce_update_theta")
+
+    def close(self) -> None:
+        if self._h:
+            self.comm.lib.cumf_dist_reduce_destroy(self._h)
+            self._h = None
+
+
+# ----------------------------------------------------------------------------------------
 # the distributed engine
 # ----------------------------------------------------------------------------------------
 
@@ -421,6 +637,24 @@ class DistALS:
         self._sse_const = None  # (sum r^2 over all ranks, lambda * n_v per Theta column): built on first use
         self._sum_r2 = None     # gather scheme: sum r^2 over all ranks (near-perfect-fit rule of the fused train SSE)
         self._fused_sse_ok = {}  # solver -> every RANK's Theta plans deliver the fused train SSE (decided collectively, once)
+        # the native half-iterations (als_dist.cpp): the product path of the HIP ops -- kernels and RCCL collectives enqueued
+        # back to back by one C call per half-iteration, no torch.distributed call and no Python in between
+        self._ncomm = self._nx = self._nt = self._nr = None
+        self._px = self._pt = None
+        if native_wanted(self.ops) and dev.type == "cuda":
+            self._ncomm = NativeComm(dev, self.group)
+            if self.scheme == "gather":
+                def side(pipe, bounds, plan, gather_rows):
+                    if pipe is not None:
+                        return NativeGather(self._ncomm, pipe[0], [p for (_, _, p) in pipe[1]], f, gather_rows)
+                    b = np.asarray(bounds, dtype=np.int64)
+                    return NativeGather(self._ncomm, np.stack([b[:-1], b[1:]], axis=1), [plan], f, gather_rows)
+
+                self._nx = side(getattr(self, "_x_pipe", None), self.xb, self.x_plan, self.n)
+                self._nt = side(getattr(self, "_t_pipe", None), self.tb, self.t_plan, self.m)
+            else:
+                self._nr = NativeReduce(self._ncomm, self.n, f, [p for (_, _, p) in self.t_batches])
+            return
         if self.scheme == "gather":
             self._gx = SlabGather(self.xb, f, torch.float32, dev, self.group)
             self._gt = SlabGather(self.tb, f, torch.float32, dev, self.group)
@@ -546,6 +780,10 @@ class DistALS:
                          sse_bins=None) -> None:
         """`gather` scheme, one side: this rank's slab of `out` from the replicated `table`, then the slabs of
         all ranks exchanged -- piece by piece under the next piece's kernel when a pipeline exists."""
+        native = self._nx if out is self.XT else self._nt
+        if native is not None:
+            native.update(colidx, val, table, out, self.lam, solver, cg_iters, sse_bins)
+            return
         r0, r1 = int(bounds[self.rank]), int(bounds[self.rank + 1])
         mine = out[r0:r1]
         if pg is not None:
@@ -622,7 +860,7 @@ class DistALS:
         key = self.solver_theta
         if key not in self._fused_sse_ok:
             ok = getattr(self.ops, "fused_sse_available", None)
-            plans = [p for (_, _, p) in self._t_pipe[1] if p is not None] if self._pt is not None else [self.t_plan]
+            plans = [p for (_, _, p) in self._t_pipe[1] if p is not None] if self._t_pipe is not None else [self.t_plan]
             mine = ok is not None and all(ok(p, self.solver_theta) for p in plans)
             flag = torch.tensor([1 if mine else 0], dtype=torch.int32)
             if dist.is_initialized() and self.world > 1:
@@ -649,6 +887,8 @@ class DistALS:
             if not train_sse:
                 return None
             t = bins.sum().reshape(1)
+            if self._ncomm is not None:
+                return self._trusted_sse(float(self._ncomm.all_reduce_f64(t).item()))
             if dist.is_initialized() and self.world > 1:
                 if dist.get_backend() != "nccl":
                     t = t.cpu()
@@ -659,6 +899,12 @@ class DistALS:
         if quad is not None:
             s_total, reg_all = self._train_sse_constants()
             terms = torch.zeros(1, dtype=torch.float64, device=self.XT.device)  # accumulated on the device, read once
+        if self._nr is not None:  # the whole Theta update in one C call (cumf_dist_reduce_update_theta)
+            self._nr.update_theta(self.lc_rowidx, self.lc_val, self.XT, self.thetaT, self.lam, self.solver_theta,
+                                  self.cg_iters_theta, reg_all if quad is not None else None, terms)
+            if quad is None:
+                return None
+            return self._trusted_sse(s_total - float(self._ncomm.all_reduce_f64(terms).item()))
         # reduce scheme (replaces hugewiki.cu:2611-2745).  Pipeline over the Theta batches:
         #   packed Gram(b) -> reduce-scatter(b) [async, RCCL stream]   ||   packed Gram(b + 1) ...
         #   wait(b) -> unpack -> solve(b) -> all-gather(b)
@@ -739,6 +985,11 @@ class DistALS:
         """Destroy the plans (the side plans, the pipeline pieces', the Theta batches') and hand the library's pooled scratch
         of this device back (tile buffers of the f >= 144 LU path, pre-split tables of gram mode "fast": up to 48 GiB
         outside torch's caching allocator)."""
+        for name in ("_nx", "_nt", "_nr", "_ncomm"):  # native objects before the plans they point at
+            obj = getattr(self, name, None)
+            if obj is not None:
+                obj.close()
+                setattr(self, name, None)
         plans = [getattr(self, "x_plan", None), getattr(self, "t_plan", None)]
         for pipe in (getattr(self, "_x_pipe", None), getattr(self, "_t_pipe", None)):
             if pipe is not None:

@@ -14,6 +14,7 @@ CSRC = os.path.join(_HERE, "csrc")
 # CUMF_ALS_LIB: load another build of the library (kernel experiments; the profiling build libALS_ablate.so)
 LIB_PATH = os.environ.get("CUMF_ALS_LIB") or os.path.join(CSRC, "libALS.so")
 MAIN_PATH = os.path.join(CSRC, "main")
+HUGEWIKI_PATH = os.path.join(CSRC, "hugewiki")  # the multi-GPU program (one process per GPU over RCCL)
 ABLATE_LIB_PATH = os.path.join(CSRC, "libALS_ablate.so")  # -DCUMF_ABLATE=1 build (tools/gram_pass_alone.py)
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
@@ -22,6 +23,13 @@ C_SYMBOLS = [
     "cumf_doALS", "cumf_doALS_ex", "cumf_plan_create", "cumf_plan_destroy", "cumf_plan_info", "cumf_plan_set_gather_rows", "cumf_gram_fast_status",
     "cumf_fused_available", "cumf_als_update_fused", "cumf_fused_sse_available", "cumf_als_update_fused_sse", "cumf_quadratic_sse_terms", "cumf_get_hermitian", "cumf_get_hermitian_packed", "cumf_get_hermitian_fp16", "cumf_cg_solve_batched_fp16", "cumf_set_tt_fp16", "cumf_get_tt_fp16", "cumf_cg_solve_batched", "cumf_lu_solve_batched",
     "cumf_pack_upper", "cumf_unpack_upper", "cumf_sse", "cumf_set_gram_mode", "cumf_get_gram_mode", "cumf_set_presplit", "cumf_get_presplit", "cumf_presplit_pitch", "cumf_presplit_table", "cumf_check_gather_table", "cumf_set_kernel_timing", "cumf_last_kernel_ms", "cumf_kernel_ms_since_reset", "cumf_last_kernel_name", "cumf_last_error", "cumf_release_scratch", "cumf_rand_init", "cumf_widen_rowptr", "cumf_als_version", "cumf_als_arch",
+]
+# every extern "C" symbol declared in include/cumf_dist_capi.h (the multi-GPU half-iterations, als_dist.cpp)
+DIST_SYMBOLS = [
+    "cumf_comm_unique_id", "cumf_comm_create", "cumf_comm_create_local", "cumf_comm_create_custom", "cumf_comm_destroy",
+    "cumf_comm_rank", "cumf_comm_world", "cumf_comm_transport_name", "cumf_comm_all_reduce_f64",
+    "cumf_dist_gather_create", "cumf_dist_gather_update", "cumf_dist_gather_destroy",
+    "cumf_dist_reduce_create", "cumf_dist_reduce_update_theta", "cumf_dist_reduce_destroy",
 ]
 # C++-linkage drop-in symbols (include/als.h, include/cg.h) under the reference's mangled names
 CXX_SYMBOLS = [
@@ -52,7 +60,7 @@ def load():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  cumf_als_amd has no CPU fallback.")
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
-    missing = [s for s in C_SYMBOLS + CXX_SYMBOLS if not hasattr(lib, s)]
+    missing = [s for s in C_SYMBOLS + DIST_SYMBOLS + CXX_SYMBOLS if not hasattr(lib, s)]
     if missing:
         raise RuntimeError(f"{LIB_PATH} lacks symbols declared in include/: {missing}")
 
@@ -131,6 +139,37 @@ def load():
     lib.cumf_rand_init.argtypes = [fp, C.c_long, C.c_float, C.c_long]
     lib.cumf_als_version.restype = C.c_int
     lib.cumf_als_arch.restype = C.c_char_p
+    # include/cumf_dist_capi.h
+    lib.cumf_comm_unique_id.restype = C.c_int
+    lib.cumf_comm_unique_id.argtypes = [vp]
+    lib.cumf_comm_create.restype = C.c_int
+    lib.cumf_comm_create.argtypes = [C.POINTER(C.c_void_p), vp, C.c_int, C.c_int]
+    lib.cumf_comm_create_local.restype = C.c_int
+    lib.cumf_comm_create_local.argtypes = [C.POINTER(C.c_void_p)]
+    lib.cumf_comm_create_custom.restype = C.c_int
+    lib.cumf_comm_create_custom.argtypes = [C.POINTER(C.c_void_p), vp, C.c_int, C.c_int]
+    lib.cumf_comm_destroy.restype = C.c_int
+    lib.cumf_comm_destroy.argtypes = [vp]
+    lib.cumf_comm_rank.restype = C.c_int
+    lib.cumf_comm_rank.argtypes = [vp]
+    lib.cumf_comm_world.restype = C.c_int
+    lib.cumf_comm_world.argtypes = [vp]
+    lib.cumf_comm_transport_name.restype = C.c_char_p
+    lib.cumf_comm_transport_name.argtypes = [vp]
+    lib.cumf_comm_all_reduce_f64.restype = C.c_int
+    lib.cumf_comm_all_reduce_f64.argtypes = [vp, vp, C.c_long, vp]
+    lib.cumf_dist_gather_create.restype = C.c_int
+    lib.cumf_dist_gather_create.argtypes = [C.POINTER(C.c_void_p), vp, vp, C.c_int, C.c_int]
+    lib.cumf_dist_gather_update.restype = C.c_int
+    lib.cumf_dist_gather_update.argtypes = [vp, vp, ip, fp, fp, fp, C.c_float, C.c_int, C.c_int, vp, vp]
+    lib.cumf_dist_gather_destroy.restype = C.c_int
+    lib.cumf_dist_gather_destroy.argtypes = [vp]
+    lib.cumf_dist_reduce_create.restype = C.c_int
+    lib.cumf_dist_reduce_create.argtypes = [C.POINTER(C.c_void_p), vp, C.c_long, C.c_int, C.c_int]
+    lib.cumf_dist_reduce_update_theta.restype = C.c_int
+    lib.cumf_dist_reduce_update_theta.argtypes = [vp, vp, ip, fp, fp, fp, C.c_float, C.c_int, C.c_int, fp, vp, vp]
+    lib.cumf_dist_reduce_destroy.restype = C.c_int
+    lib.cumf_dist_reduce_destroy.argtypes = [vp]
     host_args = [vp] * 12 + [C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_float, C.c_int, C.c_int, C.c_int,
                              C.c_int]
     lib.cumf_doALS.restype = C.c_float

@@ -6,8 +6,8 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_c_symbols():
-    text = open(os.path.join(ROOT, "include", "cumf_als_capi.h")).read()
+def _declared_c_symbols(header="cumf_als_capi.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(cumf_[A-Za-z0-9_]+)\s*\(", text)))
 
@@ -17,7 +17,9 @@ def test_header_symbols_are_exported(alslib):
 
     declared = _declared_c_symbols()
     assert set(declared) == set(lib.C_SYMBOLS), (declared, lib.C_SYMBOLS)
-    for s in declared + lib.CXX_SYMBOLS:
+    declared_dist = _declared_c_symbols("cumf_dist_capi.h")   # the multi-GPU half-iterations (als_dist.cpp)
+    assert set(declared_dist) == set(lib.DIST_SYMBOLS), (declared_dist, lib.DIST_SYMBOLS)
+    for s in declared + declared_dist + lib.CXX_SYMBOLS:
         assert hasattr(alslib, s), s
     assert alslib.cumf_als_arch() == b"gfx950"
 

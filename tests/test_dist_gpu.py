@@ -93,7 +93,7 @@ def test_hugewiki_runner_single_gpu(oracle, alslib, tmp_path):
     assert np.abs(eng.thetaT.cpu().numpy() - th0.reshape(n, f)).max() <= 2e-3 * np.abs(th0).max()
 
 
-def _rccl_worker(port, scheme, solver, d, m, n, f, lam, iters, theta0, q):
+def _rccl_worker(port, scheme, solver, d, m, n, f, lam, iters, theta0, q, native="1"):
     """One rank, backend "nccl" (= RCCL): the device-side collectives of cumf_als_amd.dist --
     reduce_scatter_tensor on the packed Gram, all_gather_into_tensor on the factor slabs -- execute
     for real, which the gloo tests (host staging) never reach."""
@@ -104,6 +104,7 @@ def _rccl_worker(port, scheme, solver, d, m, n, f, lam, iters, theta0, q):
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["CUMF_DIST_NATIVE"] = native  # "1": cumf_dist_* (als_dist.cpp) over its own RCCL communicator; "0": torch.distributed
     os.environ["CUMF_ALS_PIPE_FORCE"] = "1"  # the pipelined (async) all-gathers, on one rank ...
     os.environ["CUMF_ALS_PIPE_CHUNKS"] = "4"  # ... and on both sides (the default pipelines only factor matrices >= 32 MB)
     torch.cuda.set_device(0)
@@ -122,7 +123,13 @@ def _rccl_worker(port, scheme, solver, d, m, n, f, lam, iters, theta0, q):
                                    d["csc_indices"], d["csc_data"])
             eng = cdist.DistALS(mat, f, lam, cdist.HipOps("cuda:0"), solver=solver, cg_iters=6, scheme=scheme,
                                 theta_batch=3)
-        if scheme.startswith("gather"):
+        if eng._ncomm is not None:  # the native half-iterations own an RCCL communicator of their own
+            assert eng._ncomm.name == "rccl"
+            if scheme.startswith("gather"):
+                assert eng._nx.pieces == 4 and eng._nt.pieces == 4 and eng._px is None and eng._pt is None
+            else:
+                assert eng._nr is not None
+        elif scheme.startswith("gather"):
             assert eng._px is not None and eng._px.chunks == 4 and not eng._px.staged
             assert eng._pt is not None and eng._pt.chunks == 4 and not eng._pt.staged   # the 192 MB side is pipelined too
         eng.init_factors(theta0)
@@ -133,8 +140,9 @@ def _rccl_worker(port, scheme, solver, d, m, n, f, lam, iters, theta0, q):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("native", ["1", "0"])
 @pytest.mark.parametrize("scheme,solver", [("reduce", "lu"), ("reduce", "cg"), ("gather", "lu"), ("gather_device", "lu")])
-def test_rccl_backend_world1(oracle, alslib, scheme, solver):
+def test_rccl_backend_world1(oracle, alslib, scheme, solver, native):
     """the RCCL branches of dist.py (device tensors, no host staging, async
     reduce-scatter overlapped with the next Theta batch) run on the GPU box with world_size 1."""
     torch = pytest.importorskip("torch")
@@ -153,7 +161,7 @@ def test_rccl_backend_world1(oracle, alslib, scheme, solver):
     oracle.do_als(d, th_ref, x_ref, m, n, f, lam, iters, solver=solver)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_rccl_worker, args=(_free_port(), scheme, solver, d, m, n, f, lam, iters, theta0, q))
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), scheme, solver, d, m, n, f, lam, iters, theta0, q, native))
     p.start()
     th, x = q.get(timeout=600)
     p.join(timeout=120)
