@@ -207,6 +207,10 @@ def test_bench_hugewiki_leg_over_rccl_world1(alslib):
     hw = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert hw["scaling"] == "weak" and hw["scheme"] == "reduce" and hw["n_ranks_seen"] == 1
     assert hw["value"] > 0 and np.isfinite(hw["value"]) and hw["x_half_ms"] > 0 and hw["theta_half_ms"] > 0
+    # round 6: the leg runs on torch.distributed collectives first, then on the native half-iterations (als_dist.cpp over
+    # an RCCL communicator of their own), which take the object over; same factors either way
+    assert hw["collectives"].startswith("native") and hw["native_equals_torch_collectives"] is True, hw
+    assert hw["torch_collectives"]["value"] > 0 and hw["torch_collectives"]["x_half_ms"] > 0
 
 
 def test_pack_unpack_upper(alslib):
@@ -283,7 +287,14 @@ def test_bench_world2_branch_runs(alslib, args, launch):
     if "hugewiki" in args:
         assert "hugewiki" not in line
     else:
+        # round 6: the line was measured on torch.distributed collectives first and then taken over by the native
+        # half-iterations (cumf_dist_*: here over the custom transport, gloo); both sets of numbers are in it
+        assert line["collectives"].startswith("native") and line["native_equals_torch_collectives"] is True, line
+        assert rk["transport"] == "custom"
+        tc = line["torch_collectives"]
+        assert tc["value"] > 0 and tc["ms_per_step"] > 0 and len(tc["ranks"]["per_rank"]["x_half_ms"]) == 2
         hw = line["hugewiki"]
+        assert hw["collectives"].startswith("native") and hw["torch_collectives"]["value"] > 0, hw
         assert hw["scaling"] == "weak" and hw["scheme"] == "reduce" and hw["n_ranks_seen"] == 2 and hw["theta_batch"] == 3
         assert hw["value"] > 0 and np.isfinite(hw["value"]) and hw["ms_per_step"] > 0
         assert hw["x_half_ms"] > 0 and hw["theta_half_ms"] > 0 and set(hw["non_kernel_ms"]) == {"x", "theta"}
@@ -324,6 +335,41 @@ def test_bench_line_survives_a_failing_hugewiki_leg(alslib, fault):
     if fault == "rank1_raises":
         assert out.returncode == 0, out.stderr[-2000:]
         assert "rank 1" in line["hugewiki"]["error"] or "another rank" in line["hugewiki"]["error"]
+
+
+@pytest.mark.parametrize("fault", ["rank1_raises", "hang"])
+def test_bench_line_survives_a_failing_native_leg(alslib, fault):
+    """Round 6: the native half-iterations are measured BEHIND the line that torch.distributed collectives produced; when
+    the native leg fails (CUMF_BENCH_FAIL_NATIVE=1: agreed on by one all-reduce, both ranks skip it) the line keeps those
+    numbers, says so, and the hugewiki leg still runs; when it hangs (hang1) the LineGuard prints the line at its deadline
+    with `native: {"error": ...}`."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from tests.test_dist_cpu import _free_port
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CUMF_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1",
+               CUMF_BENCH_FAIL_NATIVE="1" if fault == "rank1_raises" else "hang1", CUMF_BENCH_LEG_DEADLINE="60")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--scale", "0.05", "--no-cpu-baseline", "--scheme", "gather"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (out.stdout[-2000:], out.stderr[-2000:])
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and np.isfinite(line["value"]) and line["ranks"]["n_ranks_seen"] == 2
+    assert "error" in line["native"] and "torch_collectives" not in line, line
+    assert len(line["ranks"]["per_rank"]["x_half_ms"]) == 2   # the diagnostics of the path the numbers come from
+    if fault == "rank1_raises":
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert line["collectives"] == "torch.distributed"
+        assert line["hugewiki"]["value"] > 0   # the next leg still ran
 
 
 def test_quadratic_sse_terms_kernel(alslib):
