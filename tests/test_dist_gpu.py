@@ -289,12 +289,18 @@ def test_bench_world2_branch_runs(alslib, args, launch):
     else:
         # round 6: the line was measured on torch.distributed collectives first and then taken over by the native
         # half-iterations (cumf_dist_*: here over the custom transport, gloo); both sets of numbers are in it
-        assert line["collectives"].startswith("native") and line["native_equals_torch_collectives"] is True, line
-        assert rk["transport"] == "custom"
-        tc = line["torch_collectives"]
-        assert tc["value"] > 0 and tc["ms_per_step"] > 0 and len(tc["ranks"]["per_rank"]["x_half_ms"]) == 2
+        # (whichever measured faster keeps the headline; over the host-staged stand-in transport that may be either)
+        assert line["native_equals_torch_collectives"] is True, line
+        if line["collectives"].startswith("native"):
+            assert rk["transport"] == "custom"
+            tc = line["torch_collectives"]
+            assert tc["value"] > 0 and tc["ms_per_step"] > 0 and len(tc["ranks"]["per_rank"]["x_half_ms"]) == 2
+        else:
+            assert line["native"]["value"] > 0 and line["native"]["ms_per_step"] > 1.02 * line["ms_per_step"]
+            assert line["native"]["transport"] == "custom"
         hw = line["hugewiki"]
-        assert hw["collectives"].startswith("native") and hw["torch_collectives"]["value"] > 0, hw
+        other = hw["torch_collectives"] if hw["collectives"].startswith("native") else hw["native"]
+        assert other["value"] > 0 and hw["native_equals_torch_collectives"] is True, hw
         assert hw["scaling"] == "weak" and hw["scheme"] == "reduce" and hw["n_ranks_seen"] == 2 and hw["theta_batch"] == 3
         assert hw["value"] > 0 and np.isfinite(hw["value"]) and hw["ms_per_step"] > 0
         assert hw["x_half_ms"] > 0 and hw["theta_half_ms"] > 0 and set(hw["non_kernel_ms"]) == {"x", "theta"}
