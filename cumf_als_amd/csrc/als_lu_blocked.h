@@ -128,6 +128,8 @@ __device__ __forceinline__ void lu_prep_step_s(const ACC& acc, LuPrepS<NB>& s, f
     // of lane group q at its column (one 16-byte load per block, steps 1 .. L; the 16 lanes of a column read one address) --
     // instead of four ds_bpermute per block: 2 L LDS instructions per panel instead of 4 L (LDS operations of one wave
     // execute in order: no barrier).
+    // (Stores by the 16 lanes of lane group q alone -- EXEC narrowed inside one asm block -- measured the same: the stores'
+    // cost is not in the lanes that carry nothing useful, profiles/r06/ab_side_rows.txt.)
     static_for<L>([&](auto bc) {
       constexpr int b = Ip + decltype(bc)::value;
       *reinterpret_cast<f32x4*>(xbuf + ((ln.kk * NB + b) * 16 + ln.c) * 4) = acc[tile_of<NB>(Ip, b)];
@@ -189,8 +191,11 @@ __device__ __forceinline__ void lu_prep_step_s(const ACC& acc, LuPrepS<NB>& s, f
     s.rsk = bperm(src, s.rsk);
   } else if constexpr (STEP == L + 7) {
     // the back substitution runs on the rows of -U that stay in the accumulators: it wants 1 / (-u_kk) (all 16 lanes of
-    // a group write the same value to the same word; p0 + kk < (f + 3) & ~3 always, a pivot past f is never read)
-    rdiag[p0 + ln.kk] = -(s.rsk * s.rsk);
+    // a group write the same value to the same word; p0 + kk < (f + 3) & ~3 always, a pivot past f is never read).
+    // Rows of a fourth panel above the last block row are read as rows of W = -U / sqrt(u_kk) instead (lu_wave_blocked: the side
+    // rows), whose diagonal is -sqrt(u_kk) = -1 / rsk.
+// (One writer per lane group -- the other lanes on words of their own -- measured the same: ab_side_rows.txt.)
+    rdiag[p0 + ln.kk] = (q == 3 && Ip < NB - 1) ? -s.rsk : -(s.rsk * s.rsk);
   } else {
     constexpr int b = Ip + STEP - (L + 8);
 #if CUMF_ABLATE

@@ -1043,14 +1043,29 @@ __device__ __forceinline__ void wave_tiles_to_global(const f32x4 (&acc)[NB * (NB
 // (LDS operations of one wave execute in order: the window is rewritten behind the reads).
 // ----------------------------------------------------------------------------------
 constexpr int kBsPitch = 17;
-// window + pivot reciprocals + 16 zeros + dummy line, then (16-byte aligned) the panel-row exchange of lu_prep_step_s:
-// 4 lane groups x NB blocks x 16 columns x 4 rows
+// window + pivot reciprocals + 16 zeros + dummy line, then (128-byte aligned) the SIDE ROWS of lu_wave_blocked: rows 12 .. 15 of
+// every tile above the last block row, as rows of W.  The panel-row exchange of lu_prep_step_s (4 lane groups x NB blocks x 16
+// columns x 4 rows = 256 NB floats) aliases the window (272 NB floats): the window is written by the back substitution only,
+// the exchange is dead by then.
+// Side store: tile t = (I, J) in a slot of kSideSlot = 80 floats, row 12 + k, column c at 80 t + skew(I) + 17 k + c with
+// skew(I) = 32 I + 12 + 16 (tile_of(I, I) & 1) (a tile's rows reach 14 floats into the next slot: the 32 I keep block rows
+// with different skews apart).  ds_read_b32 serves lanes 0 .. 31 / 32 .. 63 in one cycle each when their banks
+// (dword address mod 32) differ; the lane of row i reads the window at 17 i + j -- bank 17 i + j -- and the banks of the lanes
+// of rows 12 .. 15 (mod 16) are what the side rows must take over: 80 t + skew = 16 (I + J) + 12 (mod 32), so row 12 + k of
+// block I sits on bank 12 + 17 k + 16 I + 16 J + j -- its window bank for even J, that of its partner lane (row + 16: the other
+// side lane of the group) for odd J.  A first layout with 16-float rows (banks j and j + 16 only: five lanes per bank) cost
+// more LDS cycles than the MFMAs it replaced.
+constexpr int kSideSlot = 80;
 template <int NB>
-__host__ __device__ constexpr int wave_lu_xbuf_offset(int f) {
-  return (16 * NB * kBsPitch + ((f + 3) & ~3) + 16 + 64 + 3) & ~3;
+__host__ __device__ constexpr int wave_lu_side_offset(int f) {
+  return (16 * NB * kBsPitch + ((f + 3) & ~3) + 16 + 64 + 31) & ~31;
 }
 template <int NB>
-__host__ __device__ constexpr int wave_lu_lds_floats(int f) { return wave_lu_xbuf_offset<NB>(f) + 4 * NB * 64; }
+__host__ __device__ constexpr int wave_lu_side_skew(int I) { return 32 * I + 12 + 16 * (tile_of<NB>(I, I) & 1); }
+template <int NB>
+__host__ __device__ constexpr int wave_lu_lds_floats(int f) {
+  return wave_lu_side_offset<NB>(f) + kSideSlot * (NB * (NB + 1) / 2) + 32 * NB + 32;
+}
 template <int NB, int ARITH = kArithSplit3>
 __host__ __device__ constexpr int wave_stage_lds_floats() {
   if constexpr (ARITH == kArithPre || ARITH == kArithPrePk)
@@ -1059,9 +1074,13 @@ __host__ __device__ constexpr int wave_stage_lds_floats() {
     return 64 * 8 * NB;             // 8 NB chunks of 64 floats
 }
 
+// Round 6 (side rows): rows 12 .. 15 of the blocks above the last block row are not in the accumulators as rows of -U -- the
+// fourth panel of a block row skips its fp32 MFMAs -- but in `side` as rows of W (scaled by 1 / sqrt(u_kk), rdiag holds the
+// matching reciprocal): the lanes of those rows read tile (I, kb) of the side store, one slot further per block column,
+// instead of the window (layout and banks: wave_lu_side_offset).
 template <int NB, int NQ>
 __device__ __forceinline__ float back_substitute_tiles(const f32x4 (&acc)[NB * (NB + 1) / 2], float* T,
-                                                      const float* rdiag, const float* zpad, int f,
+                                                      const float* rdiag, const float* zpad, const float* side, int f,
                                                       float* __restrict__ x_global, int lane) {
   const int c = lane & 15, g = lane >> 4;
   const int top = f - 1;
@@ -1080,23 +1099,30 @@ __device__ __forceinline__ float back_substitute_tiles(const f32x4 (&acc)[NB * (
     });
   };
   float z[NQ], rdl[NQ];
-  const float* rowp[NQ];
+  const float* rowp[NQ];  // this lane's row in block column kb (walks down with kb for the side rows)
+  int step[NQ];           // floats per block column: kSideSlot for a side row, 0 for a row of the window
   int ib[NQ];  // block of this lane's row
   static_for<NQ>([&](auto qc) {
     constexpr int q = decltype(qc)::value;
     const int i = lane + 64 * q;
     const int ic = i < f ? i : f - 1;
-    ib[q] = i < f ? (i >> 4) : 1 << 20;  // rows past f never take part
-    rowp[q] = T + ic * kBsPitch;
+    const int I = ic >> 4;
+    ib[q] = i < f ? I : 1 << 20;  // rows past f never take part
+    const bool srow = I < NB - 1 && (ic & 15) >= 12;
+    const int tII = I * NB - I * (I - 1) / 2;  // tile_of(I, I); tile_of(I, kb) = tII + kb - I
+    const float* sp = side + (tII + (NB - 1) - I) * kSideSlot + 32 * I + 12 + 16 * (tII & 1) + 17 * (ic & 3);
+    rowp[q] = srow ? sp : T + ic * kBsPitch;
+    step[q] = srow ? kSideSlot : 0;
     rdl[q] = i < f ? rdiag[ic] : 0.f;
   });
   float col[2][16][NQ];
-  auto issue = [&](auto kbc, auto bufc) {
+  auto issue = [&](auto kbc, auto bufc) {  // called once per block column, kb = NB - 1 first
     constexpr int kb = decltype(kbc)::value, buf = decltype(bufc)::value, Q = kb >> 2;
     const float* base[Q + 1];
     static_for<Q + 1>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
       base[q] = (ib[q] > kb) ? zpad : rowp[q];
+      rowp[q] -= step[q];
     });
     static_for<16>([&](auto jc) {  // issued in the order they are consumed (LDS returns in order)
       constexpr int j = 15 - decltype(jc)::value;
@@ -1234,7 +1260,8 @@ __device__ __forceinline__ float lu_wave_blocked(f32x4 (&acc)[NB * (NB + 1) / 2]
   float* rdiag = T + 16 * NB * kBsPitch;  // pivot reciprocals, then 16 zeros (rows outside a pivot block read these)
   float* zpad = rdiag + ((f + 3) & ~3);
   if (lane < 16) zpad[lane] = 0.f;
-  float* xbuf = T + wave_lu_xbuf_offset<NB>(f);  // panel-row exchange: [lane group 4][block NB][column 16][row 4]
+  float* xbuf = T;  // panel-row exchange: [lane group 4][block NB][column 16][row 4], in the (still unused) window
+  float* side = T + wave_lu_side_offset<NB>(f);  // rows 12 .. 15 of the tiles above the last block row, as rows of W
 
   LuPrepS<NB> s;
   // bf16 planes of the w of the block row that has just been eliminated (blocks below it): the operands of its rank-16
@@ -1290,15 +1317,27 @@ __device__ __forceinline__ float lu_wave_blocked(f32x4 (&acc)[NB * (NB + 1) / 2]
 #endif
           if constexpr (TP > 0) __builtin_amdgcn_sched_barrier(0);
         });
-        // the block row's own tiles: what its next panel reads (and the rows the back substitution reads later)
+        if constexpr (q == 3 && !last_row) {
+          // Round 6: the fourth panel's update of the block row would only finish its own rows 13 .. 15 for the back
+          // substitution (no later panel reads this block row) -- and v_mfma_f32_16x16x4_f32 holds the SIMD for 36 cycles,
+          // nothing issues beside it.  Those rows are kept as rows of W instead (lane group kk = row 12 + kk; zeros at and left
+          // of the diagonal: wm), one ds_write_b32 per tile; back_substitute_tiles reads them from there.  82 instead of 109
+          // fp32 MFMAs per 100 x 100 system.
+          static_for<L>([&](auto bc2) {
+            constexpr int b = Ip + decltype(bc2)::value;
+            side[tile_of<NB>(Ip, b) * kSideSlot + wave_lu_side_skew<NB>(Ip) + 17 * ln.kk + ln.c] = b == Ip ? wm : w[q][b];
+          });
+        } else {
+          // the block row's own tiles: what its next panel reads (and the rows the back substitution reads later)
 #if CUMF_ABLATE
-        if (!(dbg & 512))
+          if (!(dbg & 512))
 #endif
-        static_for<L>([&](auto bc2) {
-          constexpr int b = Ip + decltype(bc2)::value;
-          constexpr int t = tile_of<NB>(Ip, b);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wm, w[q][b], acc[t], 0, 0, 0);
-        });
+          static_for<L>([&](auto bc2) {
+            constexpr int b = Ip + decltype(bc2)::value;
+            constexpr int t = tile_of<NB>(Ip, b);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wm, w[q][b], acc[t], 0, 0, 0);
+          });
+        }
         __builtin_amdgcn_sched_barrier(0);  // no instruction motion across panels (lu_wave: hoisted broadcasts spill)
       };
       if constexpr (exists_static) {
@@ -1344,7 +1383,7 @@ __device__ __forceinline__ float lu_wave_blocked(f32x4 (&acc)[NB * (NB + 1) / 2]
     return sum;
   }
 #endif
-  return back_substitute_tiles<NB, (16 * NB + 63) / 64>(acc, T, rdiag, zpad, f, x_global, lane);
+  return back_substitute_tiles<NB, (16 * NB + 63) / 64>(acc, T, rdiag, zpad, side, f, x_global, lane);
 }
 
 // ----------------------------------------------------------------------------------

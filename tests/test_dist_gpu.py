@@ -209,8 +209,15 @@ def test_bench_hugewiki_leg_over_rccl_world1(alslib):
     assert hw["value"] > 0 and np.isfinite(hw["value"]) and hw["x_half_ms"] > 0 and hw["theta_half_ms"] > 0
     # round 6: the leg runs on torch.distributed collectives first, then on the native half-iterations (als_dist.cpp over
     # an RCCL communicator of their own), which take the object over; same factors either way
-    assert hw["collectives"].startswith("native") and hw["native_equals_torch_collectives"] is True, hw
-    assert hw["torch_collectives"]["value"] > 0 and hw["torch_collectives"]["x_half_ms"] > 0
+    # (whichever measured faster keeps the object's own numbers -- at this scale a step is < 1 ms and either may win --
+    # the other set sits beside them)
+    assert hw["native_equals_torch_collectives"] is True, hw
+    if hw["collectives"].startswith("native"):
+        other = hw["torch_collectives"]
+    else:
+        other = hw["native"]
+        assert other["transport"] == "rccl" and other["ms_per_step"] > 1.02 * hw["ms_per_step"], hw
+    assert other["value"] > 0 and other["x_half_ms"] > 0
 
 
 def test_pack_unpack_upper(alslib):
