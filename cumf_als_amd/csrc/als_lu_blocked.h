@@ -194,7 +194,7 @@ __device__ __forceinline__ void lu_prep_step_s(const ACC& acc, LuPrepS<NB>& s, f
     // a group write the same value to the same word; p0 + kk < (f + 3) & ~3 always, a pivot past f is never read).
     // Rows of a fourth panel above the last block row are read as rows of W = -U / sqrt(u_kk) instead (lu_wave_blocked: the side
     // rows), whose diagonal is -sqrt(u_kk) = -1 / rsk.
-// (One writer per lane group -- the other lanes on words of their own -- measured the same: ab_side_rows.txt.)
+    // (One writer per lane group -- the other lanes on words of their own -- measured the same: ab_side_rows.txt.)
     rdiag[p0 + ln.kk] = (q == 3 && Ip < NB - 1) ? -s.rsk : -(s.rsk * s.rsk);
   } else {
     constexpr int b = Ip + STEP - (L + 8);
