@@ -102,6 +102,9 @@ struct KernelArgs {
   // the fp32 gather table itself (`gather` is replaced by the pre-split planes / f16 words of a launch that uses them): what
   // the Gram-free CG of short rows reads (als_short.hip)
   const float* gather_f32;
+  // the six-product forms throughout (CUMF_PRESPLIT_OFF / CUMF_PRESPLIT_VERIFY: what the bit-identity tests compare): no packed
+  // last block in the in-kernel split either (kArithSplitPk, als_wave.hip)
+  int no_pack;
 };
 constexpr int kSseBins = 1024;
 

@@ -418,6 +418,7 @@ int debug_switches() {
 }
 #endif
 
+int presplit_mode();
 KernelArgs base_args(const cumf_plan_t* p, const int* colidx, const float* val, const float* gather, int f,
                      float lambda) {
   KernelArgs a{};
@@ -437,6 +438,7 @@ KernelArgs base_args(const cumf_plan_t* p, const int* colidx, const float* val, 
   a.gather_f32 = gather;
   a.row_begin = p->row_begin;
   a.f = f;
+  a.no_pack = presplit_mode() == CUMF_PRESPLIT_OFF || presplit_mode() == CUMF_PRESPLIT_VERIFY;
   a.lambda = lambda;
 #if CUMF_ABLATE
   a.dbg = debug_switches();

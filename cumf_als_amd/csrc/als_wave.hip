@@ -65,6 +65,8 @@ typedef __attribute__((address_space(3))) float* lds_float_ptr;  // LDS pointer 
 // feature-block counts whose kernels also exist on the pre-split table (kArithPre): f = 96 .. 111 and f = 64 .. 79 -- the
 // headline f = 100 and BASELINE configs[4]'s f = 64 (presplit_nb_ok in als_internal.h is the host's copy of this list)
 #define CUMF_WAVE_PRE (CUMF_WAVE_NB == 7 || CUMF_WAVE_NB == 5)
+// feature-block counts with kArithSplitPk instances (the in-kernel split with the rating-only last block packed, f % 16 == 0)
+#define CUMF_WAVE_SPLITPK (CUMF_WAVE_NB <= 7)
 constexpr int kWaveStage = 32;   // ratings per stage = K of v_mfma_f32_16x16x32_bf16
 constexpr int kZeroFloats = 256; // >= 16 * kMaxWaveNB + 16
 
@@ -96,7 +98,13 @@ __device__ __forceinline__ f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 c) {
 // ds_read_b64_tr_b16, the 16-bit transposing read of gfx950 -- no split, no pack, no select on the VALU.  For gather
 // tables that live in the caches (the Netflix Theta side: X = 7 MB; the hugewiki X side: Theta = 16 MB); an HBM-resident
 // table stays fp32 (1.5 x the bytes would cost more than the VALU work saves).
-enum { kArithSplit3 = 0, kArithFast = 1, kArithPre = 2, kArithPrePk = 3 };
+enum { kArithSplit3 = 0, kArithFast = 1, kArithPre = 2, kArithPrePk = 3, kArithSplitPk = 4 };
+// kArithSplitPk (round 6): the in-kernel split with the last block PACKED, for f % 16 == 0 -- there the last feature block holds
+// nothing but the rating slot, and six products per tile of its column (four on its diagonal tile) multiply 15 zero columns.
+// The rating is loaded by the lanes of columns 0, 1, 2, split like a feature, and lane c keeps plane c: the packed operand
+// [r_h r_m r_l 0 ...] of kArithPrePk -- three products h_I pk + m_I pk + l_I pk per tile (all nine plane products), one (pk pk^T)
+// on the diagonal tile, folded back once per item by wave_fold_strip; the gather skips the block (no LDS-DMA, no chunk).
+// 65 instead of 80 MFMAs and 32 instead of 40 gathers per stage at f = 64.
 constexpr float kFastScale = 4096.0f;             // values must stay below 65504 / 4096 = 15.99 in magnitude
 constexpr float kFastUnscale = 1.0f / (4096.0f * 4096.0f);
 
@@ -147,7 +155,7 @@ struct WaveGather {
   bool is_feat, is_val;    // last feature block: this lane holds a feature / the rating slot
   bool has_val;            // is_val and the item has ratings (an empty row reads zeros instead)
 
-  __device__ __forceinline__ void init(const KernelArgs& a, int f, long long begin, int len_, int lane) {
+  __device__ __forceinline__ void init(const KernelArgs& a, int f, long long begin, int len_, int lane, bool pk3 = false) {
     const int c = lane & 15;
     g = lane >> 4;
     len = len_;
@@ -163,7 +171,7 @@ struct WaveGather {
     zero_base = reinterpret_cast<const char*>(g_wave_zeros) + 4 * c;
     const int fi = 16 * (NB - 1) + c;
     is_feat = fi < f;
-    is_val = fi == f;
+    is_val = pk3 ? c < 3 : fi == f;  // kArithSplitPk (f % 16 == 0): the rating in the lanes of columns 0, 1, 2
     // lanes behind the features re-read the start of the row (in bounds) and drop the value
     last_off = is_feat ? 64 * (NB - 1) : -4 * c;
     // A row without ratings still runs ONE stage, on zeros (the accumulators then flow from the stage loop into
@@ -253,14 +261,14 @@ struct WaveGather {
   // ---- prefetch through LDS: global_load_lds_dword writes lane l's dword to (LDS pointer in M0) +
   // instruction offset + 4 l, so every (rating, feature block) gather of the wave lands as one 256-byte
   // chunk, in flight without holding registers.  Chunk k = e * NB + b at floats [64 k, 64 k + 64).
-  template <bool FULL>
+  template <bool FULL, bool SKIP_LAST = false>
   __device__ __forceinline__ void dma_issue(const WaveStage<NB>& st, lds_float_ptr lds, int s) const {
     using gptr = const __attribute__((address_space(1))) void*;
     using lptr = __attribute__((address_space(3))) void*;
     static_for<8>([&](auto ec) {
       constexpr int E = decltype(ec)::value;
       const char* row = row_ptr<FULL, E>(st, s);
-      static_for<NB>([&](auto bc) {
+      static_for<SKIP_LAST ? NB - 1 : NB>([&](auto bc) {
         constexpr int B = decltype(bc)::value;
         constexpr int k = E * NB + B;
         if constexpr (B + 1 < NB) {
@@ -274,10 +282,11 @@ struct WaveGather {
     });
   }
   // chunk -> registers (after s_waitcnt vmcnt(0))
+  template <bool SKIP_LAST = false>
   __device__ __forceinline__ void dma_read(WaveStage<NB>& st, const float* lds_lane) const {
     static_for<8>([&](auto ec) {
       constexpr int E = decltype(ec)::value;
-      static_for<NB>([&](auto bc) {
+      static_for<SKIP_LAST ? NB - 1 : NB>([&](auto bc) {
         constexpr int B = decltype(bc)::value;
         st.raw[B][E] = lds_lane[64 * (E * NB + B)];
       });
@@ -291,6 +300,8 @@ struct WaveGather {
       float w = __builtin_bit_cast(float, fast_word(st.rv[E]));
       asm volatile("" : "+v"(w));  // computed by every lane, then ONE select (a conditional conversion compiles to exec-mask branches)
       st.raw[NB - 1][E] = is_feat ? st.raw[NB - 1][E] : w;
+    } else if constexpr (ARITH == kArithSplitPk) {
+      st.raw[NB - 1][E] = st.rv[E];  // no feature in the block: the rating (columns 0 .. 2) or zero
     } else
       st.raw[NB - 1][E] = is_feat ? st.raw[NB - 1][E] : st.rv[E];
   }
@@ -304,8 +315,8 @@ struct SplitState {
   float a, b, ra, rb, ta, tb;
   unsigned H, M;
 };
-template <int NB, int B, int V, int STEP>
-__device__ __forceinline__ void split_micro(const WaveStage<NB>& st, Planes<NB>& P, SplitState& x) {
+template <int NB, int B, int V, int STEP, class PL>
+__device__ __forceinline__ void split_micro(const WaveStage<NB>& st, PL& P, SplitState& x) {
   if constexpr (STEP == 0) {
     x.a = st.raw[B][2 * V];
     x.b = st.raw[B][2 * V + 1];
@@ -325,8 +336,8 @@ __device__ __forceinline__ void split_micro(const WaveStage<NB>& st, Planes<NB>&
     P.l[B][V] = pack_bf16(x.ta, x.tb);
   }
 }
-template <int NB, int B, int V>
-__device__ __forceinline__ void split_pair(const WaveStage<NB>& st, Planes<NB>& P) {
+template <int NB, int B, int V, class PL>
+__device__ __forceinline__ void split_pair(const WaveStage<NB>& st, PL& P) {
   SplitState x;
   static_for<6>([&](auto sc) { split_micro<NB, B, V, decltype(sc)::value>(st, P, x); });
 }
@@ -587,6 +598,8 @@ struct Planes<NB, kArithPrePk> {
   u32x4 h[NB], m[NB], l[NB];  // blocks 0 .. NB - 2
   u32x4 pk;                   // the last block, packed
 };
+template <int NB>
+struct Planes<NB, kArithSplitPk> : Planes<NB, kArithPrePk> {};
 
 template <int NB, bool PK>
 struct PreGather {
@@ -829,8 +842,8 @@ __host__ __device__ constexpr GramSchedPk<NB> make_gram_sched_pk() {
   }
   return s;
 }
-template <int NB, int N>
-__device__ __forceinline__ void gram_mfma_sched_pk(const Planes<NB, kArithPrePk>& P, f32x4 (&acc)[NB * (NB + 1) / 2], u32x4 (&h2)[2]) {
+template <int NB, int N, class PL>
+__device__ __forceinline__ void gram_mfma_sched_pk(const PL& P, f32x4 (&acc)[NB * (NB + 1) / 2], u32x4 (&h2)[2]) {
   constexpr GramSchedPk<NB> S = make_gram_sched_pk<NB>();
   constexpr int t = S.tile[N], kind = S.kind[N];
   constexpr int I = tile_I<NB>(t), J = tile_J<NB>(t);
@@ -897,6 +910,46 @@ __device__ __forceinline__ void wave_fold_strip(f32x4 (&acc)[NB * (NB + 1) / 2],
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[t][r] = (g == 0 && r == 0) ? rt : 0.f;
   }
+}
+
+// kArithSplitPk: stage_step (the in-kernel split) without the last block's gathers and with its packed operand.
+template <int NB, int KIND>
+__device__ __forceinline__ void stage_step_splitpk(const WaveGather<NB>& wg, Planes<NB, kArithSplitPk>& P, WaveStage<NB>& R,
+                                                   lds_float_ptr lds, const float* lds_lane, f32x4 (&acc)[NB * (NB + 1) / 2],
+                                                   int s_next, int s_idx, int c) {
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the LDS-DMA chunks have landed
+  wg.template dma_read<true>(R, lds_lane);
+  static_for<8>([&](auto ec) { wg.template finish_one<decltype(ec)::value, kArithSplitPk>(R); });  // consumes R.rv
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the chunks are in registers, the buffer is free
+  if constexpr (KIND == kStepFull) {
+    wg.template dma_issue<true, true>(R, lds, s_next);  // consumes R.idx
+    wg.template load_val<true>(R, s_next);
+    wg.template load_idx<true>(R, s_idx);
+  } else if constexpr (KIND == kStepPartial) {
+    const int nfull = wg.len / kWaveStage, nst = (wg.len + kWaveStage - 1) / kWaveStage;
+    if (s_next < nfull) {
+      wg.template dma_issue<true, true>(R, lds, s_next);
+      wg.template load_val<true>(R, s_next);
+    } else {
+      wg.template dma_issue<false, true>(R, lds, s_next);
+      wg.template load_val<false>(R, s_next);
+    }
+    if (s_idx < nfull)
+      wg.template load_idx<true>(R, s_idx);
+    else if (s_idx < nst)
+      wg.template load_idx<false>(R, s_idx);
+  }
+  static_for<4 * (NB - 1)>([&](auto uc) { split_pair<NB, decltype(uc)::value / 4, decltype(uc)::value % 4>(R, P); });
+  // the rating: lanes of column 0 keep its h, column 1 its m, column 2 its l (the other columns hold zeros in all three)
+  const bool c1 = c == 1, c2 = c == 2;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    unsigned H, M, L;
+    split3_pair(R.raw[NB - 1][2 * v], R.raw[NB - 1][2 * v + 1], H, M, L);
+    P.pk[v] = c2 ? L : (c1 ? M : H);
+  }
+  u32x4 h2[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+  static_for<GramSchedPk<NB>::N>([&](auto nc) { gram_mfma_sched_pk<NB, decltype(nc)::value>(P, acc, h2); });
 }
 
 // One stage: wait for the chunks -> rating pieces -> 6 NB transposing reads -> chunks of the next stage, indices of the one
@@ -1723,8 +1776,10 @@ __device__ __forceinline__ void fast_unscale(f32x4 (&acc)[(NB * (NB + 1) / 2 + N
 // hugewiki X side).  The kernel then has no "dump the partial tiles" exit between the Gram pass and the solver,
 // and THAT exit is what made the register allocator relocate the accumulator tiles at the hand-over and park
 // five of them in scratch (41 spilled registers, 2.9 GB of scratch writes per Netflix Theta launch; 0 without it).
+// (the CG instances of the small systems sit at the edge of three waves per SIMD -- 166 registers at NB = 5 -- and the packed form
+// went over it: 174 registers, Theta side 4.6 -> 4.95 ms at f = 64; held at three)
 template <int NB, int MODE, int FC, int ARITH = kArithSplit3, bool WHOLE = false>
-__global__ __launch_bounds__(64, CUMF_WAVE_MIN_WAVES) void als_wave_kernel(const KernelArgs a) {
+__global__ __launch_bounds__(64, (NB <= 5 && MODE == kModeCG) ? 3 : CUMF_WAVE_MIN_WAVES) void als_wave_kernel(const KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = NB * (NB + 1) / 2;
   const int lane = threadIdx.x;
@@ -1774,23 +1829,32 @@ __global__ __launch_bounds__(64, CUMF_WAVE_MIN_WAVES) void als_wave_kernel(const
         stage_step_pre<NB, kStepLast, PK>(wg, P, R, smem, acc, 0, 0);
       }
     } else {
+    constexpr bool SPK = ARITH == kArithSplitPk;
     WaveGather<NB> wg;
-    wg.init(a, f, begin, len, lane);
+    wg.init(a, f, begin, len, lane, SPK);
     WaveStage<NB> R;
     Planes<NB, ARITH> P;
     lds_float_ptr lds = (lds_float_ptr)smem;  // staging chunks of this wave (the LU window aliases them later)
     const float* lds_lane = smem + lane;
     // prologue: chunks + ratings of stage 0 in flight, indices of stage 1
     wg.template load_idx<false>(R, 0);
-    wg.template dma_issue<false>(R, lds, 0);
+    wg.template dma_issue<false, SPK>(R, lds, 0);
     wg.template load_val<false>(R, 0);
     wg.template load_idx<false>(R, clamp(1));
     int s = 0;
     // stages s + 1, s + 2 full: select-free steps; then the clamped form; the last stage of the item
     // prefetches nothing (three step bodies, each branch-free)
-    for (; s + 2 < nfull; ++s) stage_step<NB, kStepFull, ARITH>(wg, P, R, lds, lds_lane, acc, s + 1, s + 2);
-    for (; s + 1 < nst; ++s) stage_step<NB, kStepPartial, ARITH>(wg, P, R, lds, lds_lane, acc, s + 1, s + 2);
-    stage_step<NB, kStepLast, ARITH>(wg, P, R, lds, lds_lane, acc, 0, 0);  // the last stage prefetches nothing
+    if constexpr (SPK) {
+      const int c = lane & 15;
+      for (; s + 2 < nfull; ++s) stage_step_splitpk<NB, kStepFull>(wg, P, R, lds, lds_lane, acc, s + 1, s + 2, c);
+      for (; s + 1 < nst; ++s) stage_step_splitpk<NB, kStepPartial>(wg, P, R, lds, lds_lane, acc, s + 1, s + 2, c);
+      stage_step_splitpk<NB, kStepLast>(wg, P, R, lds, lds_lane, acc, 0, 0, c);
+      wave_fold_strip<NB>(acc, false, lane);
+    } else {
+      for (; s + 2 < nfull; ++s) stage_step<NB, kStepFull, ARITH>(wg, P, R, lds, lds_lane, acc, s + 1, s + 2);
+      for (; s + 1 < nst; ++s) stage_step<NB, kStepPartial, ARITH>(wg, P, R, lds, lds_lane, acc, s + 1, s + 2);
+      stage_step<NB, kStepLast, ARITH>(wg, P, R, lds, lds_lane, acc, 0, 0);  // the last stage prefetches nothing
+    }
     }
   }
   if constexpr (ARITH == kArithFast) fast_unscale<NB, 1, 0>(acc, a.fast_flag);
@@ -2225,6 +2289,17 @@ hipError_t wave_solve_launch<CUMF_WAVE_NB>(const KernelArgs& a, int mode, long n
 #endif  // CUMF_WAVE_PART == 0
 
 
+#if CUMF_WAVE_SPLITPK
+// f % 16 == 0 on the fp32 table: the packed rating block (CUMF_ALS_SPLITPK=0 keeps the six-product form)
+static bool splitpk_wanted(const KernelArgs& a) {
+  static const bool on = [] {
+    const char* e = getenv("CUMF_ALS_SPLITPK");
+    return !(e && *e == '0');
+  }();
+  return on && !a.no_pack && !a.pre_words && !a.fast_words && (a.f & 15) == 0;
+}
+#endif
+
 #if CUMF_WAVE_PART == 1 && CUMF_WAVE_NB <= 7
 // ---- part 1: the LU form of the wave-per-item kernel
 template <int NB, int FC, int ARITH, bool WHOLE>
@@ -2263,6 +2338,9 @@ hipError_t wave_lu_launch<CUMF_WAVE_NB>(const KernelArgs& a, long n_items, hipSt
                             : launch_wave_lu<CUMF_WAVE_NB, 0, kArithPre>(a, n_items, stream);
 #endif
   if (a.pre_words) return hipErrorInvalidValue;
+#if CUMF_WAVE_SPLITPK
+  if (splitpk_wanted(a)) return launch_wave_lu<CUMF_WAVE_NB, 0, kArithSplitPk>(a, n_items, stream);
+#endif
   return a.fast_words ? launch_wave_lu<CUMF_WAVE_NB, 0, kArithFast>(a, n_items, stream)
                       : launch_wave_lu<CUMF_WAVE_NB, 0, kArithSplit3>(a, n_items, stream);
 }
@@ -2342,6 +2420,9 @@ hipError_t wave_item_launch<CUMF_WAVE_NB>(const KernelArgs& a, int mode, long n_
                             : launch_wave_fc<CUMF_WAVE_NB, 0, kArithPre>(a, mode, n_items, stream);
 #endif
   if (a.pre_words) return hipErrorInvalidValue;
+#if CUMF_WAVE_SPLITPK
+  if (mode != kModeMaterialize && splitpk_wanted(a)) return launch_wave_fc<CUMF_WAVE_NB, 0, kArithSplitPk>(a, mode, n_items, stream);
+#endif
   return a.fast_words ? launch_wave_fc<CUMF_WAVE_NB, 0, kArithFast>(a, mode, n_items, stream)
                       : launch_wave_fc<CUMF_WAVE_NB, 0, kArithSplit3>(a, mode, n_items, stream);
 #endif

@@ -226,6 +226,9 @@ int cumf_get_gram_mode(void);
  *                             CUMF_PRESPLIT_VERIFY: like ON, with the last block unpacked -- the same operands in the same
  *                             MFMA slots as the in-kernel split, BIT-IDENTICAL results (what the tests compare).  Also the
  *                             environment variable CUMF_ALS_PRESPLIT=0|1|2 read at the first half-iteration.
+ *                             OFF and VERIFY select the six-product forms THROUGHOUT: AUTO / ON also let the in-kernel split
+ *                             multiply a last feature block that holds nothing but the rating slot (f % 16 == 0, f <= 96) as
+ *                             one packed operand (same error class as the packed pre-split form; no gather of that block).
  *   cumf_presplit_table       writes the planes of a rows x f table (device pointers; rows of cumf_presplit_pitch(f) bytes:
  *                             [h: 16 FB bf16][m][l][strip of f % 16 features: h, m, l, 8 zero bytes], FB = f / 16); what the
  *                             fused calls do internally -- exported so that callers and tests can check the planes.

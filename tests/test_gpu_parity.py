@@ -1112,6 +1112,25 @@ def test_presplit_is_bit_identical(alslib, f, solver):
     assert o["packed_sse_rel_diff"] is None or o["packed_sse_rel_diff"] < 1e-6, o
 
 
+@pytest.mark.parametrize("solver", ["lu", "cg"])
+@pytest.mark.parametrize("f", [16, 32, 48, 64, 80, 96])
+def test_packed_rating_block_matches_six_product_form(alslib, f, solver):
+    """Round 6, kArithSplitPk: at f % 16 == 0 the last feature block holds nothing but the rating slot, and the in-kernel split
+    multiplies it as ONE packed operand [r_h r_m r_l 0 ...] (three products per tile of its column instead of six, all nine plane
+    products of the rating kept; no gather of the block) -- what the library picks by itself ("auto") wherever the table is not
+    pre-split.  Against the six-product form (cumf_set_presplit(CUMF_PRESPLIT_OFF)) on rows of 0, 1, 31, 32, 33, ... ratings, a
+    chunked row of 9 000 and 150 random ones: same NaN pattern, factors within 2e-5 of their scale (the bound of the packed
+    pre-split form; only the right-hand side column and sum r^2 see other roundings), fused train SSE to 1e-6."""
+    _need_gpu()
+    o = _presplit_tool().check_fused(f, solver, modes=("off", "auto"))
+    arith = lambda k: o[k].split(",")[3].strip().rstrip(">")
+    assert arith("kernel_off") == "0", o
+    # (f = 96 with a small table: "auto" pre-splits it -- the packed pre-split form, the same bound)
+    assert arith("kernel_auto") == ("3" if f == 96 else "4"), o
+    assert o["packed_nan_pattern_equal"] and o["packed_max_rel_diff"] < 2e-5, o
+    assert o["packed_sse_rel_diff"] is None or o["packed_sse_rel_diff"] < 1e-6, o
+
+
 def test_presplit_auto_follows_the_table_size(alslib, monkeypatch):
     """CUMF_PRESPLIT_AUTO: a table whose planes fit the cache budget (64 MB) takes the pre-split kernels, a larger one (the
     Netflix X side gathers 192 MB of Theta) keeps the fp32 table: there the bytes are the roof."""

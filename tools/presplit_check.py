@@ -59,8 +59,10 @@ def check_planes(f: int, rows: int = 257) -> dict:
             "h_plus_m_plus_l_exact": bool(np.array_equal(s, t.astype(np.float64)))}
 
 
-def check_fused(f: int, solver: str, seed: int = 0) -> dict:
-    """Rows of every length class (0, 1, 31, 32, 33, 64, ~200, one chunked) through the fused call, twice."""
+def check_fused(f: int, solver: str, seed: int = 0, modes=("off", "verify", "on")) -> dict:
+    """Rows of every length class (0, 1, 31, 32, 33, 64, ~200, one chunked) through the fused call, once per mode.
+    modes = ("off", "auto"): the six-product in-kernel split against what the library picks by itself -- at f % 16 == 0 on a
+    table it does not pre-split, the in-kernel split with the packed rating block (kArithSplitPk)."""
     rng = np.random.RandomState(seed + f)
     n_cols = 3000
     lens = [0, 1, 2, 31, 32, 33, 63, 64, 65, 96, 100, 127, 128, 129, 200, 255, 256, 500, 9000] + list(rng.randint(1, 400, 150))
@@ -74,7 +76,7 @@ def check_fused(f: int, solver: str, seed: int = 0) -> dict:
     plan = als.Plan(rowptr, f)
     ci, va, ga = (torch.from_numpy(v).cuda() for v in (colidx, val, gather))
     out = {}
-    for mode in ("off", "verify", "on"):
+    for mode in modes:
         als.set_presplit(mode)
         x = torch.from_numpy(x0.copy()).cuda()
         bins = als.update_fused_sse(plan, ci, va, ga, x, 0.05, solver, 6) if als.fused_sse_available(plan, solver) else None
@@ -83,23 +85,27 @@ def check_fused(f: int, solver: str, seed: int = 0) -> dict:
         torch.cuda.synchronize()
         out[mode] = (x.cpu().numpy(), None if bins is None else bins.cpu().numpy(), als.last_kernel_name())
     als.set_presplit("auto")
-    a, b, c = out["off"][0], out["verify"][0], out["on"][0]
+    first, last = modes[0], modes[-1]
+    a, c = out[first][0], out[last][0]
+    b = out["verify"][0] if "verify" in out else a
     same = bool(np.array_equal(a, b, equal_nan=True))
     fin = np.isfinite(a) & np.isfinite(c)
     sse = None
-    if out["off"][1] is not None:
-        so, sp = float(out["off"][1].sum()), float(out["on"][1].sum())
+    if out[first][1] is not None:
+        so, sp = float(out[first][1].sum()), float(out[last][1].sum())
         sse = abs(so - sp) / max(abs(so), 1e-30)
-    return {"case": "fused", "f": f, "solver": solver, "rows": len(lens), "nnz": nnz, "chunked_rows": plan.n_multi_rows,
-            "kernel_off": out["off"][2], "kernel_verify": out["verify"][2], "kernel_on": out["on"][2],
+    res = {"kernel_" + m: out[m][2] for m in modes}
+    res.update({"case": "fused", "f": f, "solver": solver, "rows": len(lens), "nnz": nnz, "chunked_rows": plan.n_multi_rows,
             # verification form (last block unpacked): the in-kernel split's bits
-            "bit_identical": same,
-            "sse_bins_identical": None if out["off"][1] is None else bool(np.array_equal(out["off"][1], out["verify"][1])),
+            "bit_identical": same if "verify" in out else None,
+            "sse_bins_identical": None if (out[first][1] is None or "verify" not in out)
+            else bool(np.array_equal(out[first][1], out["verify"][1])),
             "rows_differing": int((~np.all((a == b) | (np.isnan(a) & np.isnan(b)), axis=1)).sum()),
             # production form (last block packed): same error class, other bits in the last block column
             "packed_nan_pattern_equal": bool(np.array_equal(np.isnan(a), np.isnan(c))),
             "packed_max_rel_diff": float(np.abs(a[fin] - c[fin]).max() / np.abs(a[fin]).max()) if fin.any() else None,
-            "packed_sse_rel_diff": sse}
+            "packed_sse_rel_diff": sse})
+    return res
 
 
 def time_netflix(f: int, solver: str, reps: int) -> dict:
