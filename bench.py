@@ -961,12 +961,19 @@ def main() -> int:
         pipe_peak = 2500.0 if wave else MFMA_F32_PEAK_TFLOPS
         nnz_gpu = r.nnz
 
+        def issued_by(name):
+            # round 6: the instances with a PACKED last block (4th template argument 3 = kArithPrePk, 4 = kArithSplitPk) multiply
+            # its column by three products instead of six (one instead of four on its diagonal tile): 3 nb fewer MFMAs
+            args = (name or "").split("<")[-1].split(",")
+            packed = "als_wave_kernel" in (name or "") and len(args) >= 4 and args[3].strip() in ("3", "4")
+            return issued - (3 * nb * 512.0 if packed else 0.0)
+
         def side(ms, nbytes, key, name):
             ach = nbytes / (ms * 1e-3) / 1e9
             return {"kernel": name, "ms": ms, "alg_bytes": nbytes, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
                     "traffic": (traffic.get(key) or {}).get("bytes_per_launch"),
                     "gram_tflops_useful": float(nnz_gpu) * f * (f + 1) / (ms * 1e-3) / 1e12,
-                    "matrix_pipe_frac_issued": float(nnz_gpu) * issued / (ms * 1e-3) / 1e12 / pipe_peak}
+                    "matrix_pipe_frac_issued": float(nnz_gpu) * issued_by(name) / (ms * 1e-3) / 1e12 / pipe_peak}
 
         xs, ts = sum(x_ms) / len(x_ms), sum(t_ms) / len(t_ms)
         gram_only = None
