@@ -6,8 +6,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("scheme,solver", [("gather", "lu"), ("reduce", "lu"), ("reduce", "cg")])
-def test_world2_hip_matches_single_process(oracle, alslib, scheme, solver):
+# f = 32: f % 16 == 0, the in-kernel split with the packed rating block (kArithSplitPk) under both schemes
+@pytest.mark.parametrize("scheme,solver,f", [("gather", "lu", 20), ("reduce", "lu", 20), ("reduce", "cg", 20),
+                                             ("gather", "lu", 32), ("reduce", "cg", 32)])
+def test_world2_hip_matches_single_process(oracle, alslib, scheme, solver, f):
     torch = pytest.importorskip("torch")
     if not torch.cuda.is_available():
         pytest.fail("-m gpu tests need a GPU")
@@ -17,7 +19,7 @@ def test_world2_hip_matches_single_process(oracle, alslib, scheme, solver):
     from tests import dist_helpers
     from tests.test_dist_cpu import _free_port
 
-    m, n, f, lam, iters = 120, 90, 20, 0.05, 2
+    m, n, lam, iters = 120, 90, 0.05, 2
     r = datagen.synth_ratings(m, n, 6000, 600, seed=12, row_alpha=1.1)
     d = r.numpy()
     theta0 = (0.2 * np.random.RandomState(0).random_sample((n, f))).astype(np.float32)
